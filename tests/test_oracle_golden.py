@@ -1,0 +1,122 @@
+"""The CPU oracle (oracle/) against the golden vectors captured from the imported
+reference (oracle/make_goldens.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import crnn_ref, metrics_ref
+
+
+def _sd(d, prefix="sd."):
+    return {k[len(prefix):]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith(prefix)}
+
+
+def test_g1_sed_forward_and_grads():
+    d = load_golden("g1_sed_c8.npz")
+    m = crnn_ref.SedNetRef(conv_channels=8, dropout=0.0)
+    m.load_state_dict(_sd(d))                      # identical keys/shapes as the reference
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x).numpy(), d["logits_eval"], atol=1e-5, rtol=1e-5)
+    m.train()
+    out = m(x)
+    loss = crnn_ref.bce_logits(out, y)
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), d["logits_train"], atol=1e-5, rtol=1e-5)
+    assert abs(loss.item() - float(d["loss_train"])) < 1e-6
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), d["grad." + k], atol=2e-6, rtol=1e-4, err_msg=k)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), d["after." + k], atol=1e-6, rtol=1e-5, err_msg=k)
+
+
+def test_g3_adam_trajectory():
+    d = load_golden("g3_sed_c8_traj.npz")
+    m = crnn_ref.SedNetRef(conv_channels=8, dropout=0.0)
+    m.load_state_dict(_sd(d, "sd0."))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    batches = [(torch.from_numpy(d[f"x{i}"]), torch.from_numpy(d[f"y{i}"])) for i in range(3)]
+    losses = []
+    for ep in range(2):
+        tot = 0.0
+        for xb, yb in batches:
+            l, _ = crnn_ref.fit_step(m, opt, xb, yb)
+            tot += l.item()
+        losses.append(tot / 3)
+    np.testing.assert_allclose(losses, d["train_losses"], atol=1e-3)
+    m.eval()
+    with torch.no_grad():
+        preds = np.concatenate([torch.sigmoid(m(xb)).numpy() for xb, _ in batches])
+    np.testing.assert_allclose(preds, d["val_preds"], atol=1e-3)
+    sc = metrics_ref.compute_scores(preds > 0.5, d["val_labels"], 5)
+    assert sc["f1_overall_1sec"] == pytest.approx(float(d["val_f1_1s"]), abs=1e-12)
+    assert sc["er_overall_1sec"] == pytest.approx(float(d["val_er_1s"]), abs=1e-12)
+
+
+def test_g4_lightning_net_and_focal():
+    d = load_golden("g4_lightning.npz")
+    m = crnn_ref.LightningNetRef(dropout=0.0)
+    m.load_state_dict(_sd(d))
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x).numpy(), d["logits_eval"], atol=1e-5, rtol=1e-5)
+    m.train()
+    loss = crnn_ref.focal_bce(m(x), y)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss_train"])) < 1e-6
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), d["grad." + k], atol=2e-6, rtol=1e-4, err_msg=k)
+    lg, tg = torch.from_numpy(d["focal_logits"]), torch.from_numpy(d["focal_targets"])
+    assert crnn_ref.focal_bce(lg, tg).item() == pytest.approx(float(d["focal_mean"]), rel=1e-6)
+    assert crnn_ref.focal_bce(lg, tg, reduction="sum").item() == pytest.approx(float(d["focal_sum"]), rel=1e-6)
+    # Adam(lr=1e-3, weight_decay=1e-4) step (crnn_lightning.py:195-197)
+    opt = torch.optim.Adam(m.parameters(), lr=float(d["opt_lr"]), weight_decay=float(d["opt_wd"]))
+    opt.step()
+    for k, v in m.state_dict().items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_allclose(v.numpy(), d["sd1." + k], atol=1e-6, rtol=1e-5, err_msg=k)
+
+
+def test_g5_full_width_from_seed():
+    d = load_golden("g5_sed_c128.npz")
+    m = crnn_ref.SedNetRef(conv_channels=128, dropout=0.0)
+    m.load_state_dict(crnn_ref.rs_state_dict(m, seed=int(d["weight_seed"])))
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m(x).numpy(), d["logits_eval"], atol=1e-5, rtol=1e-4)
+    m.train()
+    out = m(x)
+    crnn_ref.bce_logits(out, y).backward()
+    np.testing.assert_allclose(out.detach().numpy(), d["logits_train"], atol=1e-5, rtol=1e-4)
+    named = dict(m.named_parameters())
+    for k in d:
+        if k.startswith("grad.") and k[5:] in named:
+            np.testing.assert_allclose(named[k[5:]].grad.numpy(), d[k], atol=1e-5, rtol=1e-3, err_msg=k)
+
+
+def test_g6_metrics_known_answers():
+    d = load_golden("g6_metrics.npz")
+    p, t = d["p"], d["t"]
+    sc = metrics_ref.compute_scores(p > 0.5, t, 5)
+    assert sc["f1_overall_1sec"] == float(d["f1_1s"]) == 0.8888888888888887
+    assert sc["er_overall_1sec"] == float(d["er_1s"]) == 0.125
+    assert metrics_ref.f1_framewise(p > 0.5, t) == float(d["f1_fr"]) == 0.34146341463414626
+    assert metrics_ref.er_framewise(p > 0.5, t) == float(d["er_fr"]) == 1.588235294117647
+    # uint8 inputs give the same answers
+    assert metrics_ref.f1_1sec((p > 0.5).astype(np.uint8), t.astype(np.uint8), 5) == float(d["f1_1s"])
+    p6, t6 = d["p6"], d["t6"]
+    sc = metrics_ref.compute_scores(p6 > 0.5, t6, 4)
+    assert sc["f1_overall_1sec"] == float(d["k6_f1_1s"])
+    assert sc["er_overall_1sec"] == float(d["k6_er_1s"])
+    assert metrics_ref.f1_framewise((p6 > 0.5).astype(np.uint8), t6.astype(np.uint8)) == float(d["k6_f1_fr"])
+    assert metrics_ref.er_framewise((p6 > 0.5).astype(np.uint8), t6.astype(np.uint8)) == float(d["k6_er_fr"])
+    z, o = np.zeros((4, 8, 1), np.float32), np.ones((4, 8, 1), np.float32)
+    assert metrics_ref.f1_1sec(o, z, 5) == float(d["edge_nref0_nsys_f1"]) == 0.0
+    assert np.isinf(metrics_ref.er_1sec(o, z, 5)) and np.isinf(d["edge_nref0_nsys_er"])
+    assert np.isnan(metrics_ref.er_1sec(z, z, 5)) and np.isnan(d["edge_allzero_er"])
+    assert metrics_ref.f1_1sec(z, z, 5) == float(d["edge_allzero_f1"])
