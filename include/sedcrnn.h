@@ -1,0 +1,243 @@
+/*
+ * sedcrnn.h — flat C ABI of libsedcrnn.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * This is the drop-in boundary of the SEDnet hot path.  The
+ * reference (noamzilo/sed-crnn) has no FFI of its own for this path: it reaches
+ * native code only through torch.nn modules, so each entry point below cites the
+ * reference call site whose ATen kernel it replaces (paths are relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensors are fp32 device memory unless noted;
+ *   - the CALLER owns every buffer (inputs, outputs, workspace); the library never
+ *     allocates or frees device memory and keeps no pointer past return;
+ *   - every launch is asynchronous on the hipStream_t passed as `stream`
+ *     (void*; NULL = the default stream); no entry synchronises the device;
+ *   - return value: 0 = ok, <0 = argument / shape error, >0 = hipError_t.  The message
+ *     of the last failure on the calling thread is sed_last_error_string().
+ *
+ * Activation layout inside the conv stack is channels-last: act[b][t][f][c]
+ * ("(seq, mel, chan)"), c contiguous.  The network input keeps the reference layout
+ * x[b][cin][f][t] (sed.py:105) and the GRU input keeps the reference feature order
+ * feat = c*F + f (sed.py:108-110), so reference state_dicts load unchanged.
+ */
+#ifndef SEDCRNN_H
+#define SEDCRNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SED_MAX_CONV 4
+#define SED_MAX_GRU 4
+#define SED_MAX_DENSE 4
+
+/* ───────────── library ───────────── */
+int sed_version(void);                       /* 10000*major + 100*minor + patch */
+const char* sed_last_error_string(void);     /* thread-local, never NULL */
+
+/* ───────────── conv 3x3, stride 1, zero pad 1 (sed.py:88,107; crnn_lightning.py:47) ─────────────
+ * w_oihw is the reference/PyTorch weight [Cout][Cin][3][3] (kh over mel, kw over time).
+ * sed_conv3x3_pack_weights lays it out for the kernels:
+ *   wp_fwd  [9][Cout][Cin]  tap-major, ci contiguous           (forward)
+ *   wp_dgrad[9][Cin][Cout]  taps flipped, ci/co swapped        (data gradient = conv of dy)
+ * either output pointer may be NULL. */
+int sed_conv3x3_pack_weights(const float* w_oihw, float* wp_fwd, float* wp_dgrad,
+                             int Cout, int Cin, void* stream);
+
+/* Number of per-block partial rows sed_conv3x3_fwd writes into `stat_partials`
+ * ([rows][2][Cout]: sum and sum of squares of the outputs, pre-BN, bias included). */
+int sed_conv3x3_stat_rows(int B, int Cin, int F, int T, int Cout, int x_is_nchw);
+
+/* y[b][t][f][co] = bias[co] + sum_{kh,kw,ci} w[co][ci][kh][kw] x[.. f+kh-1, t+kw-1 ..]
+ * x_is_nchw=1: x is the network input [B][Cin][F][T]; 0: x is channels-last [B][T][F][Cin].
+ * wp = wp_fwd from sed_conv3x3_pack_weights ([9][Cout][Cin]).
+ * bias may be NULL; stat_partials may be NULL (no statistics). */
+int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias,
+                    float* y, float* stat_partials,
+                    int B, int Cin, int F, int T, int Cout, void* stream);
+
+/* Weight gradient (aten::convolution_backward, reached from loss.backward() sed.py:137).
+ * dw_oihw[co][ci][kh][kw] = sum_pos x[pos+tap][ci] * dy[pos][co].  dy is channels-last.
+ * workspace: sed_conv3x3_wgrad_workspace_bytes(). Deterministic (fixed-order slab reduce). */
+size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout);
+int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
+                      void* workspace, int B, int Cin, int F, int T, int Cout, void* stream);
+
+/* ───────────── BatchNorm2d + ReLU + MaxPool2d + Dropout (sed.py:89-92,107; crnn_lightning.py:48-52) ─────────────
+ * Training statistics: reduce the conv partials in a fixed order (double accumulation),
+ * write mean/rstd and the fused scale/shift (scale = gamma*rstd, shift = beta - mean*scale),
+ * update running_mean / running_var (momentum, unbiased var) like nn.BatchNorm2d.
+ * count = B*T*F elements per channel. */
+int sed_bn_finalize_train(const float* stat_partials, int rows, int C, double count,
+                          const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* Eval: scale/shift from the running statistics. */
+int sed_bn_finalize_eval(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int C,
+                         float* scale, float* shift, void* stream);
+
+/* out = dropout(maxpool_{pool_f x pool_t}(relu(scale*y + shift))).
+ * y [B][T][F][C] channels-last.  out_tcf=0: out [B][T/pt][F/pf][C];
+ * out_tcf=1: out [B][T/pt][C][F/pf]  (the GRU feature order c*F'+f, sed.py:108-110).
+ * drop_p=0 or training=0 disables dropout; the keep mask is a counter-based hash of
+ * (seed, logical element index) so the backward pass regenerates it. */
+int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* shift, float* out,
+                              int B, int T, int F, int C, int pool_f, int pool_t, int out_tcf,
+                              float drop_p, uint64_t seed, void* stream);
+
+/* Backward of the block above (training statistics).  Two passes:
+ *  reduce: partials [rows][2][C] of  sum g  and  sum g*xhat  where g is dout routed through
+ *          dropout, max-pool arg-max (first maximum wins) and ReLU;
+ *  apply : dy = scale*(g - sum_g/N - xhat*sum_gx/N); also dgamma = sum_gx, dbeta = sum_g and
+ *          the conv-bias gradient partials sum dy.  Fixed-order reductions. */
+int sed_bn_bwd_rows(int B, int T, int pool_t);   /* partial rows written by the two passes below */
+int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const float* scale,
+                                     const float* shift, const float* mean, const float* rstd,
+                                     float* partials, int B, int T, int F, int C, int pool_f,
+                                     int pool_t, int out_tcf, float drop_p, uint64_t seed, void* stream);
+int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
+                        float* dgamma, float* dbeta, void* stream);
+int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd,
+                                    const float* sum_g, const float* sum_gx, float* dy,
+                                    float* dbias_partials, int B, int T, int F, int C, int pool_f,
+                                    int pool_t, int out_tcf, float drop_p, uint64_t seed, void* stream);
+/* out[c] = sum_r partials[r][c] in row order (double accumulation). */
+int sed_reduce_rows(const float* partials, int rows, int C, int row_stride, float* out, void* stream);
+
+/* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
+ * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.
+ * A(i,k) = A[i*a_si + k*a_sk], B(k,j) = B[k*b_sk + j*b_sj]; for each operand one of the
+ * two strides must be 1.  Exact fp32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
+int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
+                 float* C, long ldc, const float* bias, float beta, int M, int N, int K, void* stream);
+
+/* Small dense layer y = act(x W^T + b) for the time-distributed head (sed.py:103,112;
+ * crnn_lightning.py:63-64,72-73). x [M][K], W [N][K], y [M][N]; relu=1 applies ReLU. */
+int sed_linear_fwd(const float* x, const float* W, const float* b, float* y,
+                   int M, int K, int N, int relu, void* stream);
+/* dy is modified in place when relu=1 (masked by y>0).  dx may be NULL.
+ * workspace: sed_linear_bwd_workspace_bytes(). */
+size_t sed_linear_bwd_workspace_bytes(int M, int K, int N);
+int sed_linear_bwd(const float* x, const float* W, const float* y, float* dy, float* dx,
+                   float* dW, float* db, void* workspace, int M, int K, int N, int relu, void* stream);
+
+/* ───────────── bidirectional GRU layer recurrence (nn.GRU, sed.py:101-102,111) ─────────────
+ * PyTorch gate convention (r,z,n): n = tanh(gi_n + r*(W_hn h + b_hn)), h' = (1-z)*n + z*h, h0 = 0.
+ * gi   [B][T][2][3H]  input projections x W_ih^T + b_ih of both directions (dir 1 = reverse);
+ * whh  2 pointers to weight_hh [3H][H]; bhh 2 pointers to bias_hh [3H];
+ * out  [B][T][2H]  (forward | reverse), exactly nn.GRU's batch_first output;
+ * saved[B][T][2][5][H] = r, z, n, (W_hn h + b_hn), h_prev  (training only, may be NULL). */
+size_t sed_gru_seq_workspace_bytes(int H);          /* scratch for the transposed W_hh */
+int sed_gru_seq_fwd(const float* gi, const float* const* whh, const float* const* bhh,
+                    float* out, float* saved, void* workspace, int B, int T, int H, void* stream);
+/* dout [B][T][2H] -> dgi [B][T][2][3H] (grad of gi) and dgh [B][T][2][3H] (grad of W_hh h + b_hh). */
+int sed_gru_seq_bwd(const float* dout, const float* saved, const float* const* whh,
+                    float* dgi, float* dgh, int B, int T, int H, void* stream);
+
+/* ───────────── loss heads (sed.py:136,160; crnn_lightning.py:27-35) ─────────────
+ * kind 0: BCEWithLogits mean; kind 1: focal (alpha, gamma, log(pt+1e-12)); reduction_mean=0 -> sum.
+ * loss (1 float), dlogits (may be NULL) = d loss / d logits, probs (may be NULL) = sigmoid(logits). */
+int sed_loss_fwd_bwd(const float* logits, const float* targets, int n, int kind, float alpha,
+                     float gamma, int reduction_mean, float* loss, float* dlogits, float* probs,
+                     void* stream);
+int sed_sigmoid(const float* x, float* y, int n, void* stream);
+
+/* ───────────── optimiser (torch.optim.Adam sed.py:159; crnn_lightning.py:195-197; clip train_lightning.py:50) ─────────────
+ * sq-norm: norm_out[0] = ||g||_2, norm_out[1] = clip coefficient min(1, max_norm/(norm+1e-6))
+ * (1 when max_norm <= 0).  workspace >= sed_sqnorm_workspace_bytes(n). Deterministic. */
+size_t sed_sqnorm_workspace_bytes(long n);
+int sed_grad_norm_clip_coef(const float* g, long n, float max_norm, float* norm_out,
+                            void* workspace, void* stream);
+/* Adam with coupled L2 weight decay on a flat arena; grads are multiplied by *grad_scale
+ * (device pointer, may be NULL = 1) first.  step >= 1. */
+int sed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* grad_scale,
+                  void* stream);
+
+/* ───────────── log-mel front end (feature.py:55-59 via librosa.stft / filters.mel) ─────────────
+ * pcm [n_samples] mono f32 -> out [n_frames][n_mels] = log(mel @ |STFT|^2), n_frames = 1 + n_samples/hop.
+ * window [n_fft], melfb [n_mels][n_fft/2+1] and twiddle [n_fft/2][2] (cos,-sin of 2*pi*k/n_fft) are
+ * supplied by the host (computed in double).  pad_mode 0 = zeros ("constant"), 1 = reflect.
+ * mu/inv_sigma (may be NULL) fuse feature.py:127-129's StandardScaler: (x-mu)*inv_sigma. n_fft must be 2048. */
+int sed_logmel(const float* pcm, long n_samples, const float* window, const float* twiddle,
+               const float* melfb, const float* mu, const float* inv_sigma, float* out,
+               int n_fft, int hop, int n_mels, int pad_mode, void* stream);
+
+/* ───────────── whole-network plan (TimePooledCRNN.forward sed.py:105-112 / crnn_lightning.py:66-73) ───────────── */
+typedef struct sed_net_cfg {
+    int B, Cin, F, T;                 /* input x [B][Cin][F][T] */
+    int n_conv;
+    int C[SED_MAX_CONV];              /* conv channels */
+    int pool_f[SED_MAX_CONV], pool_t[SED_MAX_CONV];
+    float drop_p[SED_MAX_CONV];       /* dropout after block i (0 = none) */
+    int n_gru;
+    int H[SED_MAX_GRU];               /* hidden size per direction of each stacked BiGRU layer */
+    int n_dense;
+    int D[SED_MAX_DENSE];             /* dense sizes; ReLU between layers, last = classes (logits) */
+    float bn_eps, bn_momentum;
+} sed_net_cfg;
+
+typedef struct sed_net_params {      /* pointers in the reference's own layouts */
+    float* conv_w[SED_MAX_CONV];      /* [C][Cin][3][3] */
+    float* conv_b[SED_MAX_CONV];
+    float* bn_g[SED_MAX_CONV];
+    float* bn_b[SED_MAX_CONV];
+    float* bn_rm[SED_MAX_CONV];       /* running stats (params struct only; unused in grads) */
+    float* bn_rv[SED_MAX_CONV];
+    float* gru_wih[SED_MAX_GRU][2];   /* [3H][in]  (dir 1 = *_reverse) */
+    float* gru_whh[SED_MAX_GRU][2];   /* [3H][H] */
+    float* gru_bih[SED_MAX_GRU][2];
+    float* gru_bhh[SED_MAX_GRU][2];
+    float* dense_w[SED_MAX_DENSE];    /* [out][in] */
+    float* dense_b[SED_MAX_DENSE];
+} sed_net_params;
+
+/* Output time steps / features of the conv stack for cfg (T', F'); returns <0 on a bad cfg. */
+int sed_net_out_shape(const sed_net_cfg* cfg, int* Tp, int* Fp);
+size_t sed_net_workspace_bytes(const sed_net_cfg* cfg, int training);
+/* logits [B][T'][D_last].  training=1: batch statistics, dropout, activations kept in `workspace`
+ * for sed_net_backward; running stats updated in place. */
+int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float* x, float* logits,
+                    void* workspace, int training, uint64_t seed, void* stream);
+/* Gradients of every parameter into `g` (same layouts as `p`; written, not accumulated).
+ * Stages let the host overlap the gradient all-reduce with the rest of backward:
+ *   stage 0 = dense head + GRU stack, stage s>=1 = conv block (n_conv - s).  Run stages
+ *   [stage_begin, stage_end) in increasing order; (0, n_conv+1) = everything. */
+int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
+                     const float* x, const float* dlogits, void* workspace, uint64_t seed,
+                     int stage_begin, int stage_end, void* stream);
+
+/* ───────────── in-library kernel timers (measurement only; off by default) ─────────────
+ * When a tag's bit is set in `tag_mask`, every launch of that kernel family is bracketed by a pair of
+ * hipEvents on the launch stream and tagged with its algorithmic work (FLOPs for the MFMA kernels,
+ * bytes for the streaming ones).  sed_prof_read waits for the recorded events and returns the totals
+ * since the last sed_prof_enable.  Process-wide state, not thread-safe; costs nothing when disabled. */
+enum sed_kernel_tag {
+    SED_K_CONV_MFMA_FWD = 0,   /* units: FLOPs */
+    SED_K_CONV_SMALL_FWD,      /* units: bytes */
+    SED_K_CONV_MFMA_WGRAD,     /* units: FLOPs */
+    SED_K_CONV_SMALL_WGRAD,    /* units: bytes */
+    SED_K_BN_FWD,              /* units: bytes */
+    SED_K_BN_BWD_REDUCE,       /* units: bytes */
+    SED_K_BN_BWD_APPLY,        /* units: bytes */
+    SED_K_GEMM,                /* units: FLOPs */
+    SED_K_GRU_FWD,             /* units: FLOPs */
+    SED_K_GRU_BWD,             /* units: FLOPs */
+    SED_K_ADAM,                /* units: bytes */
+    SED_K_COUNT
+};
+int sed_prof_enable(unsigned tag_mask);
+int sed_prof_read(int tag, double* total_ms, long* launches, double* total_units);
+const char* sed_prof_tag_name(int tag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEDCRNN_H */

@@ -1,0 +1,400 @@
+// bnpool.hip — BatchNorm2d statistics + fused normalise/ReLU/max-pool/dropout, forward and backward.
+//
+// Replaces aten::native_batch_norm(+_backward), clamp_min/threshold_backward,
+// max_pool2d_with_indices(+_backward) and bernoulli_/mul reached from reference
+// sed.py:89-92,107 and crnn_lightning.py:48-52.  All kernels are pure HBM streaming passes over the
+// channels-last conv output: one wave covers 64 lanes x 16 B = two full 128-channel rows.
+// Reductions are two-stage, fixed order (deterministic=True, train_lightning.py:47), no float atomics.
+#include "common.h"
+
+#define BN_MAX_BLOCKS 1024
+
+// ───────────────────────── statistics ─────────────────────────
+// block = 32 channels x 32 row slices; partials [rows][2][C]
+__global__ __launch_bounds__(1024) void bn_finalize_train_k(
+    const float* __restrict__ part, int rows, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+    float eps, float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
+    float* __restrict__ shift_o) {
+    __shared__ double s1[32][33], s2[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = sl; r < rows; r += 32) {
+            a += (double)part[(size_t)r * 2 * C + c];
+            q += (double)part[(size_t)r * 2 * C + C + c];
+        }
+    s1[sl][cl] = a;
+    s2[sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double A = 0.0, Q = 0.0;
+        for (int s = 0; s < 32; ++s) { A += s1[s][cl]; Q += s2[s][cl]; }
+        double m = A / count;
+        double var = Q / count - m * m;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma[c], bt = beta[c];
+        mean_o[c] = (float)m;
+        rstd_o[c] = rstd;
+        float sc = g * rstd;
+        scale_o[c] = sc;
+        shift_o[c] = bt - (float)m * sc;
+        if (rmean) {
+            double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+extern "C" int sed_bn_finalize_train(const float* part, int rows, int C, double count, const float* gamma,
+                                     const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                     float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    SED_REQUIRE(part && gamma && beta && mean && rstd && scale && shift, "bn_finalize_train: null pointer");
+    SED_REQUIRE(rows > 0 && C > 0 && count > 0, "bn_finalize_train: bad sizes rows=%d C=%d", rows, C);
+    bn_finalize_train_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(part, rows, C, count, gamma, beta, rmean, rvar,
+                                                                      momentum, eps, mean, rstd, scale, shift);
+    SED_LAUNCH_CHECK("bn_finalize_train");
+    return 0;
+}
+
+__global__ void bn_finalize_eval_k(const float* g, const float* b, const float* rm, const float* rv, float eps,
+                                   int C, float* scale, float* shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float sc = g[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = b[c] - rm[c] * sc;
+}
+
+extern "C" int sed_bn_finalize_eval(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                    float eps, int C, float* scale, float* shift, void* stream) {
+    SED_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, "bn_finalize_eval: bad arguments");
+    bn_finalize_eval_k<<<cdiv(C, 256), 256, 0, as_stream(stream)>>>(gamma, beta, rm, rv, eps, C, scale, shift);
+    SED_LAUNCH_CHECK("bn_finalize_eval");
+    return 0;
+}
+
+// out[c] = sum_r part[r*row_stride + c]
+__global__ __launch_bounds__(1024) void reduce_rows_k(const float* __restrict__ part, int rows, int C,
+                                                      int row_stride, float* __restrict__ out) {
+    __shared__ double s1[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0;
+    if (c < C)
+        for (int r = sl; r < rows; r += 32) a += (double)part[(size_t)r * row_stride + c];
+    s1[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double A = 0.0;
+        for (int s = 0; s < 32; ++s) A += s1[s][cl];
+        out[c] = (float)A;
+    }
+}
+
+extern "C" int sed_reduce_rows(const float* part, int rows, int C, int row_stride, float* out, void* stream) {
+    SED_REQUIRE(part && out && rows > 0 && C > 0 && row_stride >= C, "reduce_rows: bad arguments");
+    reduce_rows_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(part, rows, C, row_stride, out);
+    SED_LAUNCH_CHECK("reduce_rows");
+    return 0;
+}
+
+// ───────────────────────── forward: normalise + ReLU + pool + dropout ─────────────────────────
+// channels-last output: one thread per output float4.
+__global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_k(
+    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    const int Tp = T / pt, Fp = F / pf, C4 = C >> 2;
+    const size_t n = (size_t)B * Tp * Fp * C4;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        size_t pos = i / C4;
+        int fp = (int)(pos % Fp);
+        size_t bt = pos / Fp;                       // b*Tp + tp
+        int tp = (int)(bt % Tp);
+        size_t b = bt / Tp;
+        f32x4 sc = *(const f32x4*)(scale + c4 * 4), sh = *(const f32x4*)(shift + c4 * 4);
+        f32x4 m = {0, 0, 0, 0};                     // relu(max) == max(0, ...)
+        for (int dt = 0; dt < pt; ++dt)
+            for (int df = 0; df < pf; ++df) {
+                f32x4 v = *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
+                v = v * sc + sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+            }
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] *= sed_drop_mult(seed, i * 4 + k, drop_p, inv_keep);
+        }
+        *(f32x4*)(out + i * 4) = m;
+    }
+}
+
+// GRU-order output [B][Tp][C][Fp]: one block per (b,tp) row group, LDS transpose.
+__global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_tcf_k(
+    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [Fp][C+1]
+    const int Tp = T / pt, Fp = F / pf, C4 = C >> 2, LD = C + 1;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    for (int bt = blockIdx.x; bt < B * Tp; bt += gridDim.x) {
+        int tp = bt % Tp;
+        size_t b = bt / Tp;
+        __syncthreads();
+        for (int i = threadIdx.x; i < Fp * C4; i += 256) {
+            int c4 = i % C4, fp = i / C4;
+            f32x4 sc = *(const f32x4*)(scale + c4 * 4), sh = *(const f32x4*)(shift + c4 * 4);
+            f32x4 m = {0, 0, 0, 0};
+            for (int dt = 0; dt < pt; ++dt)
+                for (int df = 0; df < pf; ++df) {
+                    f32x4 v = *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
+                    v = v * sc + sh;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], v[k]);
+                }
+            if (drop_p > 0.f) {
+                size_t oi = (((size_t)bt * Fp + fp) * C4 + c4) * 4;      // logical channels-last index
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tile[fp * LD + c4 * 4 + k] = m[k];
+        }
+        __syncthreads();
+        float* o = out + (size_t)bt * C * Fp;
+        for (int i = threadIdx.x; i < C * Fp; i += 256) {
+            int c = i / Fp, fp = i - c * Fp;
+            o[i] = tile[fp * LD + c];
+        }
+    }
+}
+
+static int check_pool(const char* who, int B, int T, int F, int C, int pf, int pt) {
+    SED_REQUIRE(B > 0 && T > 0 && F > 0 && C > 0 && pf > 0 && pt > 0, "%s: bad shape", who);
+    SED_REQUIRE(C % 4 == 0, "%s: C must be a multiple of 4 (got %d)", who, C);
+    SED_REQUIRE(T % pt == 0 && F % pf == 0, "%s: T=%d / F=%d must be divisible by the pool (%d,%d)", who, T, F, pt, pf);
+    return 0;
+}
+
+extern "C" int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* shift, float* out, int B,
+                                         int T, int F, int C, int pf, int pt, int out_tcf, float drop_p,
+                                         uint64_t seed, void* stream) {
+    SED_REQUIRE(y && scale && shift && out, "bn_relu_pool_drop_fwd: null pointer");
+    SED_TRY(check_pool("bn_relu_pool_drop_fwd", B, T, F, C, pf, pt));
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_relu_pool_drop_fwd: drop_p=%f out of [0,1)", drop_p);
+    hipStream_t s = as_stream(stream);
+    const int Tp = T / pt, Fp = F / pf;
+    SedProfScope prof(SED_K_BN_FWD, s, 4.0 * B * C * ((double)T * F + (double)Tp * Fp));
+    if (!out_tcf) {
+        size_t n = (size_t)B * Tp * Fp * (C / 4);
+        int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        bn_relu_pool_drop_fwd_k<<<grid, 256, 0, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed);
+    } else {
+        size_t lds = (size_t)Fp * (C + 1) * sizeof(float);
+        SED_REQUIRE(lds <= 150 * 1024, "bn_relu_pool_drop_fwd: F'*C tile too large for LDS");
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_fwd_tcf_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int grid = B * Tp < 4096 ? B * Tp : 4096;
+        bn_relu_pool_drop_fwd_tcf_k<<<grid, 256, lds, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed);
+    }
+    SED_LAUNCH_CHECK("bn_relu_pool_drop_fwd");
+    return 0;
+}
+
+// ───────────────────────── backward ─────────────────────────
+extern "C" int sed_bn_bwd_rows(int B, int T, int pool_t) {
+    long r = (long)B * (T / (pool_t > 0 ? pool_t : 1));
+    return (int)(r < BN_MAX_BLOCKS ? r : BN_MAX_BLOCKS);
+}
+
+// MODE 0: reduce (partials [grid][2][C] of sum g, sum g*xhat)
+// MODE 1: apply  (dy, and dbias partials [grid][C])
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
+    const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ dy,
+    float* __restrict__ partials, int B, int T, int F, int C, int pf, int pt, int out_tcf, float drop_p,
+    uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Tp = T / pt, Fp = F / pf, C4 = C >> 2, LD = C + 1;
+    float* tile = smem;                                   // [Fp][C+1] (tcf only)
+    const int tid = threadIdx.x;
+    const int nslots = 256 / C4 > 0 ? 256 / C4 : 1;       // C4 <= 256 checked by the host
+    const int c4 = tid % C4, slot = tid / C4;
+    const bool active = slot < nslots;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float invN = 1.f / ((float)B * (float)T * (float)F);
+
+    f32x4 sc = {0, 0, 0, 0}, sh = sc, mu = sc, rs = sc, sg = sc, sgx = sc;
+    if (active) {
+        sc = *(const f32x4*)(scale + c4 * 4);
+        sh = *(const f32x4*)(shift + c4 * 4);
+        mu = *(const f32x4*)(mean + c4 * 4);
+        rs = *(const f32x4*)(rstd + c4 * 4);
+        if (MODE == 1) {
+            sg = *(const f32x4*)(sum_g + c4 * 4) * invN;
+            sgx = *(const f32x4*)(sum_gx + c4 * 4) * invN;
+        }
+    }
+    f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+
+    for (int bt = blockIdx.x; bt < B * Tp; bt += gridDim.x) {
+        int tp = bt % Tp;
+        size_t b = bt / Tp;
+        if (out_tcf) {
+            __syncthreads();
+            const float* d = dout + (size_t)bt * C * Fp;
+            for (int i = tid; i < C * Fp; i += 256) {
+                int c = i / Fp, fp = i - c * Fp;
+                tile[fp * LD + c] = d[i];
+            }
+            __syncthreads();
+        }
+        if (!active) continue;
+        for (int fp = slot; fp < Fp; fp += nslots) {
+            f32x4 g;
+            if (out_tcf) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = tile[fp * LD + c4 * 4 + k];
+            } else {
+                g = *(const f32x4*)(dout + (((size_t)bt * Fp + fp) * C4 + c4) * 4);
+            }
+            if (drop_p > 0.f) {
+                size_t oi = (((size_t)bt * Fp + fp) * C4 + c4) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+            }
+            // locate the first maximum of the window (max_pool2d keeps the first index on ties)
+            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            f32x4 bx = {0, 0, 0, 0};
+            int bidx[4] = {0, 0, 0, 0};
+            int widx = 0;
+            for (int df = 0; df < pf; ++df)               // window order = (f, t): row-major over (H=F, W=T)
+                for (int dt = 0; dt < pt; ++dt, ++widx) {
+                    f32x4 v = *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
+                    f32x4 z = v * sc + sh;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (z[k] > best[k]) { best[k] = z[k]; bx[k] = (v[k] - mu[k]) * rs[k]; bidx[k] = widx; }
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!(best[k] > 0.f)) g[k] = 0.f;          // ReLU gate
+            if (MODE == 0) {
+                a1 += g;
+                a2 += g * bx;
+            } else {
+                widx = 0;
+                for (int df = 0; df < pf; ++df)
+                    for (int dt = 0; dt < pt; ++dt, ++widx) {
+                        size_t off = (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4;
+                        f32x4 v = *(const f32x4*)(y + off);
+                        f32x4 o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float xh = (v[k] - mu[k]) * rs[k];
+                            float gk = (bidx[k] == widx) ? g[k] : 0.f;
+                            o[k] = sc[k] * (gk - sg[k] - xh * sgx[k]);
+                        }
+                        *(f32x4*)(dy + off) = o;
+                        a1 += o;
+                    }
+            }
+        }
+    }
+    // block reduction of the per-thread partial sums, fixed slot order
+    __syncthreads();
+    float* red = smem;                                    // [nslots][2][C]
+    if (active) {
+        *(f32x4*)(red + (slot * 2 + 0) * C + c4 * 4) = a1;
+        if (MODE == 0) *(f32x4*)(red + (slot * 2 + 1) * C + c4 * 4) = a2;
+    }
+    __syncthreads();
+    const int nout = (MODE == 0 ? 2 : 1) * C;
+    for (int i = tid; i < nout; i += 256) {
+        int which = i / C, c = i - which * C;
+        float a = 0.f;
+        for (int s = 0; s < nslots; ++s) a += red[(s * 2 + which) * C + c];
+        partials[(size_t)blockIdx.x * nout + i] = a;
+    }
+}
+
+static size_t bwd_lds(int F, int C, int pf, int out_tcf) {
+    size_t red = (size_t)2 * 256 * 4 * sizeof(float) + 2 * C * sizeof(float);
+    size_t t = out_tcf ? (size_t)(F / pf) * (C + 1) * sizeof(float) : 0;
+    return red > t ? red : t;
+}
+
+extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const float* scale,
+                                                const float* shift, const float* mean, const float* rstd,
+                                                float* partials, int B, int T, int F, int C, int pf, int pt,
+                                                int out_tcf, float drop_p, uint64_t seed, void* stream) {
+    SED_REQUIRE(y && dout && scale && shift && mean && rstd && partials, "bn_bwd_reduce: null pointer");
+    SED_TRY(check_pool("bn_bwd_reduce", B, T, F, C, pf, pt));
+    SED_REQUIRE(C / 4 <= 256, "bn_bwd_reduce: C=%d too large (max 1024)", C);
+    size_t lds = bwd_lds(F, C, pf, out_tcf);
+    SED_REQUIRE(lds <= 150 * 1024, "bn_bwd_reduce: tile too large for LDS");
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int grid = sed_bn_bwd_rows(B, T, pt);
+    SedProfScope prof(SED_K_BN_BWD_REDUCE, as_stream(stream), 4.0 * B * C * ((double)T * F + (double)(T / pt) * (F / pf)));
+    bn_relu_pool_drop_bwd_k<0><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, nullptr, nullptr,
+                                                                       nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed);
+    SED_LAUNCH_CHECK("bn_bwd_reduce");
+    return 0;
+}
+
+__global__ void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, float* sum_g, float* sum_gx,
+                                  float* dgamma, float* dbeta) {
+    __shared__ double s1[32][33], s2[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = sl; r < rows; r += 32) {
+            a += (double)part[(size_t)r * 2 * C + c];
+            q += (double)part[(size_t)r * 2 * C + C + c];
+        }
+    s1[sl][cl] = a;
+    s2[sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double A = 0.0, Q = 0.0;
+        for (int s = 0; s < 32; ++s) { A += s1[s][cl]; Q += s2[s][cl]; }
+        sum_g[c] = (float)A;
+        sum_gx[c] = (float)Q;
+        if (dbeta) dbeta[c] = (float)A;
+        if (dgamma) dgamma[c] = (float)Q;
+    }
+}
+
+extern "C" int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
+                                   float* dgamma, float* dbeta, void* stream) {
+    SED_REQUIRE(partials && sum_g && sum_gx && rows > 0 && C > 0, "bn_bwd_finalize: bad arguments");
+    bn_bwd_finalize_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta);
+    SED_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const float* scale,
+                                               const float* shift, const float* mean, const float* rstd,
+                                               const float* sum_g, const float* sum_gx, float* dy,
+                                               float* dbias_partials, int B, int T, int F, int C, int pf, int pt,
+                                               int out_tcf, float drop_p, uint64_t seed, void* stream) {
+    SED_REQUIRE(y && dout && scale && shift && mean && rstd && sum_g && sum_gx && dy && dbias_partials,
+                "bn_bwd_apply: null pointer");
+    SED_TRY(check_pool("bn_bwd_apply", B, T, F, C, pf, pt));
+    SED_REQUIRE(C / 4 <= 256, "bn_bwd_apply: C=%d too large (max 1024)", C);
+    size_t lds = bwd_lds(F, C, pf, out_tcf);
+    SED_REQUIRE(lds <= 150 * 1024, "bn_bwd_apply: tile too large for LDS");
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int grid = sed_bn_bwd_rows(B, T, pt);
+    SedProfScope prof(SED_K_BN_BWD_APPLY, as_stream(stream), 4.0 * B * C * (2.0 * T * F + (double)(T / pt) * (F / pf)));
+    bn_relu_pool_drop_bwd_k<1><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, sum_g, sum_gx, dy,
+                                                                       dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed);
+    SED_LAUNCH_CHECK("bn_bwd_apply");
+    return 0;
+}

@@ -1,0 +1,83 @@
+// common.h — shared helpers for libsedcrnn (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sedcrnn.h"
+
+#define SED_EINVAL (-1)
+#define SED_EUNSUPPORTED (-2)
+
+void sed_set_error(const char* fmt, ...);
+
+#define SED_REQUIRE(cond, ...)                     \
+    do {                                           \
+        if (!(cond)) {                             \
+            sed_set_error(__VA_ARGS__);            \
+            return SED_EINVAL;                     \
+        }                                          \
+    } while (0)
+
+#define SED_LAUNCH_CHECK(name)                                                      \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            sed_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return (int)e__;                                                        \
+        }                                                                           \
+    } while (0)
+
+#define SED_TRY(expr)            \
+    do {                         \
+        int r__ = (expr);        \
+        if (r__ != 0) return r__; \
+    } while (0)
+
+// measurement-only launch bracket (see sed_prof_enable); no-op unless the tag is enabled
+extern unsigned g_sed_prof_mask;
+void sed_prof_begin(int tag, hipStream_t s, double units);
+void sed_prof_end(int tag, hipStream_t s);
+struct SedProfScope {
+    int tag; hipStream_t s; bool on;
+    SedProfScope(int tag_, hipStream_t s_, double units) : tag(tag_), s(s_), on((g_sed_prof_mask >> tag_) & 1u) {
+        if (on) sed_prof_begin(tag, s, units);
+    }
+    ~SedProfScope() { if (on) sed_prof_end(tag, s); }
+};
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef __HIPCC__
+// ── counter-based dropout hash: same (seed, idx) -> same keep decision in fwd and bwd ──
+__device__ __forceinline__ uint32_t sed_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+// uniform in [0,1) with 24 bits
+__device__ __forceinline__ float sed_uniform(uint64_t seed, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = sed_fmix32(lo ^ (uint32_t)seed);
+    h = sed_fmix32(h + (uint32_t)(seed >> 32) + hi * 0x9E3779B1u);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+// multiplier applied to a kept/dropped element (0 or 1/(1-p)); p==0 -> 1
+__device__ __forceinline__ float sed_drop_mult(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    return (sed_uniform(seed, idx) >= p) ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+#endif

@@ -1,0 +1,553 @@
+// conv.hip — 3x3 / stride 1 / zero-pad 1 convolution over (mel, time), channels-last.
+//
+// Replaces aten::mkldnn_convolution / convolution_backward reached from nn.Conv2d at
+// reference sed.py:88,107 and crnn_lightning.py:47.
+//
+// Two code paths (gfx950 only):
+//   * small  : Cin*Cout small (first layer, Cin in {1,2,4}; the 16-channel Lightning net).
+//              Direct VALU convolution, HBM-bound: coalesced 16 B/lane channel-last stores,
+//              mel-band halo tile + weights staged in LDS.
+//   * mfma   : Cin%32==0, Cout%32==0 (the 128-channel layers, K = 9*Cin = 1152): implicit GEMM
+//              on v_mfma_f32_32x32x2_f32 (exact fp32), (TT+2)x(F+2) halo tile of 32 input
+//              channels in LDS read with conflict-free ds_read_b128, weights double-buffered.
+// Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
+// conv output is not re-read for the statistics.
+#include "common.h"
+
+#define CV_CIC 32   // input channels per LDS chunk
+#define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
+#define CV_MTW 5    // max 32-row tiles per wave
+
+struct ConvPlan {
+    int kind;       // 0 small, 1 mfma, -1 unsupported
+    int TT;         // time rows per block tile
+    int nct;        // mfma: 32-wide co tiles per block
+    int tblocks;    // ceil(T/TT)
+    int rows;       // stat partial rows = B * tblocks
+    size_t lds;
+};
+
+static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+    ConvPlan p{};
+    p.kind = -1;
+    if (!x_is_nchw && Cin % CV_CIC == 0 && Cout % 32 == 0) {
+        int nct = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0 ? 2 : 1);
+        int mparts = 4 / nct;
+        int limit = 32 * CV_MTW * mparts;
+        if (F <= limit) {
+            int TT = limit / F;
+            if (TT > T) TT = T;
+            if (TT > 8) TT = 8;
+            p.kind = 1; p.TT = TT; p.nct = nct;
+            p.lds = ((size_t)(TT + 2) * (F + 2) * CV_LD + 2 * 32 * nct * CV_LD) * sizeof(float);
+        }
+    }
+    if (p.kind < 0) {
+        if (Cout % 4 != 0) return p;
+        int TT = 4;
+        if (TT > T) TT = T;
+        size_t lds = ((size_t)9 * Cin * Cout + (size_t)(TT + 2) * (F + 2) * Cin) * sizeof(float);
+        size_t red = (size_t)2 * 256 * 4 * sizeof(float);
+        if (lds < red) lds = red;
+        if (lds > 150 * 1024) return p;
+        p.kind = 0; p.TT = TT; p.nct = 0; p.lds = lds;
+    }
+    p.tblocks = cdiv(T, p.TT);
+    p.rows = B * p.tblocks;
+    return p;
+}
+
+// ───────────────────────── weight packing ─────────────────────────
+__global__ void conv_pack_w_k(const float* __restrict__ w, float* __restrict__ wf,
+                              float* __restrict__ wd, int Cout, int Cin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cout * Cin * 9;
+    if (i >= n) return;
+    int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    float v = w[i];
+    if (wf) wf[((size_t)tap * Cout + co) * Cin + ci] = v;
+    // dgrad: dx[pos][ci] = sum_tap' sum_co dy[pos + tap' - 1][co] * w[co][ci][flip(tap')]
+    if (wd) wd[((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+}
+
+extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(w && Cout > 0 && Cin > 0, "conv3x3_pack_weights: bad arguments");
+    int n = Cout * Cin * 9;
+    conv_pack_w_k<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(w, wf, wd, Cout, Cin);
+    SED_LAUNCH_CHECK("conv_pack_w");
+    return 0;
+}
+
+// ───────────────────────── small direct forward ─────────────────────────
+__global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w_s = smem;                        // [9][Cin][Cout]
+    float* halo = smem + 9 * Cin * Cout;      // [TT+2][F+2][Cin]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int F2 = F + 2;
+
+    for (int i = tid; i < 9 * Cin * Cout; i += 256) {
+        int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+        w_s[(tap * Cin + ci) * Cout + co] = wp[i];
+    }
+    const int hn = (TT + 2) * F2 * Cin;
+    if (x_nchw) {
+        for (int i = tid; i < hn; i += 256) {         // tt fastest: time is contiguous in NCHW
+            int tt = i % (TT + 2), ff = (i / (TT + 2)) % F2, ci = i / ((TT + 2) * F2);
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * Cin + ci) * F + f) * T + t];
+            halo[(tt * F2 + ff) * Cin + ci] = v;
+        }
+    } else {
+        for (int i = tid; i < hn; i += 256) {
+            int ci = i % Cin, ff = (i / Cin) % F2, tt = i / (Cin * F2);
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * T + t) * F + f) * Cin + ci];
+            halo[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const int ncg = Cout >> 2;
+    const int nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (active) {
+        f32x4 bv = {0, 0, 0, 0};
+        if (bias) bv = *(const f32x4*)(bias + cg * 4);
+        for (int p = slot; p < TT * F; p += nslots) {
+            int tl = p / F, f = p - tl * F;
+            if (t0 + tl >= T) break;
+            f32x4 acc = bv;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * Cin;
+                    const float* wq = w_s + ((kh * 3 + kw) * Cin) * Cout + cg * 4;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        float xv = hp[ci];
+                        f32x4 w4 = *(const f32x4*)(wq + ci * Cout);
+                        acc += xv * w4;
+                    }
+                }
+            *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4) = acc;
+            s1 += acc;
+            s2 += acc * acc;
+        }
+    }
+    if (stat) {
+        __syncthreads();
+        float* red = smem;                     // [2][nslots][Cout]
+        if (active) {
+            *(f32x4*)(red + (slot)*Cout + cg * 4) = s1;
+            *(f32x4*)(red + (nslots + slot) * Cout + cg * 4) = s2;
+        }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * Cout; i += 256) {
+            int which = i / Cout, co = i - which * Cout;
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * Cout + co];
+            stat[row * 2 * Cout + i] = a;
+        }
+    }
+}
+
+// ───────────────────────── MFMA implicit-GEMM forward ─────────────────────────
+// grid (ceil(T/TT), B, Cout/(32*NCT)); 256 threads = 4 waves.
+// wave w: co tile ct = w % NCT, row part mp = w / NCT; row tiles mt = mp + i*(4/NCT).
+template <int NCT>
+__global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
+    constexpr int MPARTS = 4 / NCT;
+    constexpr int WROWS = 32 * NCT;                 // weight rows (co) per block
+    constexpr int WV4 = WROWS * 8 / 256;            // float4 per thread per weight tile (= NCT)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    const int HR = (TT + 2) * F2;
+    float* halo = smem;                             // [HR][CV_LD]
+    float* wbuf = smem + HR * CV_LD;                // [2][WROWS][CV_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
+    const int ct = wave % NCT, mp = wave / NCT;
+    const int MROWS = TT * F;
+    const int nMT = (MROWS + 31) >> 5;
+
+    int abase[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int p = (mp + i * MPARTS) * 32 + r;
+        if (p >= MROWS) p = MROWS - 1;
+        int tl = p / F, f = p - tl * F;
+        abase[i] = (tl * F2 + f) * CV_LD + 4 * h;
+    }
+    const int bbase = (ct * 32 + r) * CV_LD + 4 * h;
+
+    f32x16 acc[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const int nchunks = Cin / CV_CIC;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        __syncthreads();
+        // stage the halo tile of this 32-channel chunk (zero padded)
+        for (int i = tid; i < HR * 8; i += 256) {
+            int row = i >> 3, q = i & 7;
+            int tt = row / F2, ff = row - tt * F2;
+            int t = t0 + tt - 1, f = ff - 1;
+            f32x4 v = {0, 0, 0, 0};
+            if (t >= 0 && t < T && f >= 0 && f < F)
+                v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
+            *(f32x4*)(halo + row * CV_LD + q * 4) = v;
+        }
+        // weights of tap 0
+#pragma unroll
+        for (int u = 0; u < WV4; ++u) {
+            int i = tid + u * 256, row = i >> 3, q = i & 7;
+            f32x4 v = *(const f32x4*)(wp + ((size_t)(0 * Cout + co0 + row)) * Cin + cc * CV_CIC + q * 4);
+            *(f32x4*)(wbuf + row * CV_LD + q * 4) = v;
+        }
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x4 wn[WV4];
+            if (tap < 8) {
+#pragma unroll
+                for (int u = 0; u < WV4; ++u) {
+                    int i = tid + u * 256, row = i >> 3, q = i & 7;
+                    wn[u] = *(const f32x4*)(wp + ((size_t)((tap + 1) * Cout + co0 + row)) * Cin + cc * CV_CIC + q * 4);
+                }
+            }
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = (kw * F2 + kh) * CV_LD;
+            const float* wb = wbuf + (tap & 1) * WROWS * CV_LD + bbase;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bf = *(const f32x4*)(wb + g * 8);
+                f32x4 af[CV_MTW];
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i)
+                    af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < CV_MTW; ++i)
+                        if (mp + i * MPARTS < nMT)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[j], acc[i], 0, 0, 0);
+            }
+            if (tap < 8) {
+                float* wdst = wbuf + ((tap + 1) & 1) * WROWS * CV_LD;
+#pragma unroll
+                for (int u = 0; u < WV4; ++u) {
+                    int i = tid + u * 256, row = i >> 3, q = i & 7;
+                    *(f32x4*)(wdst + row * CV_LD + q * 4) = wn[u];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    // epilogue: bias, channel-last store, BatchNorm partial sums
+    const int co = co0 + ct * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int mt = mp + i * MPARTS;
+        if (mt < nMT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                int p = mt * 32 + row;
+                int tl = p / F, f = p - tl * F;
+                if (p < MROWS && t0 + tl < T) {
+                    float v = acc[i][j] + bv;
+                    y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+    }
+    if (stat) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();
+        float* red = smem;                          // [4 waves][2][32]
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        if (tid < 2 * WROWS) {
+            int which = tid / WROWS, c = tid - which * WROWS;       // c in [0, 32*NCT)
+            int cti = c >> 5, cr = c & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
+extern "C" int sed_conv3x3_stat_rows(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+    ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
+    return p.kind >= 0 ? p.rows : 0;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { sed_set_error("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
+}
+
+extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
+                               float* stat, int B, int Cin, int F, int T, int Cout, void* stream) {
+    SED_REQUIRE(x && wp && y, "conv3x3_fwd: null pointer");
+    SED_REQUIRE(B > 0 && Cin > 0 && F > 0 && T > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d Cin=%d F=%d T=%d Cout=%d", B, Cin, F, T, Cout);
+    ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
+    SED_REQUIRE(p.kind >= 0, "conv3x3_fwd: unsupported shape Cin=%d Cout=%d F=%d (need Cout%%4==0 and a tile that fits LDS)", Cin, Cout, F);
+    hipStream_t s = as_stream(stream);
+    const double npos = (double)B * T * F;
+    SedProfScope prof(p.kind == 0 ? SED_K_CONV_SMALL_FWD : SED_K_CONV_MFMA_FWD, s,
+                      p.kind == 0 ? 4.0 * npos * (Cin + Cout) : 2.0 * 9.0 * Cin * Cout * npos);
+    if (p.kind == 0) {
+        SED_TRY(set_lds(conv3x3_small_fwd_k, p.lds));
+        conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+    } else {
+        dim3 grid(p.tblocks, B, Cout / (32 * p.nct));
+        if (p.nct == 4) {
+            SED_TRY(set_lds(conv3x3_mfma_fwd_k<4>, p.lds));
+            conv3x3_mfma_fwd_k<4><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+        } else if (p.nct == 2) {
+            SED_TRY(set_lds(conv3x3_mfma_fwd_k<2>, p.lds));
+            conv3x3_mfma_fwd_k<2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+        } else {
+            SED_TRY(set_lds(conv3x3_mfma_fwd_k<1>, p.lds));
+            conv3x3_mfma_fwd_k<1><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+        }
+    }
+    SED_LAUNCH_CHECK("conv3x3_fwd");
+    return 0;
+}
+
+// ───────────────────────── weight gradient ─────────────────────────
+struct WgradPlan {
+    int kind;        // 0 small, 1 mfma
+    int TT, ntiles, ngroups, tblocks;
+    size_t lds, slab_floats;
+};
+
+static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+    WgradPlan p{};
+    p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0 && (F % 2 == 0)) ? 1 : 0;
+    if (p.kind == 1) {
+        p.TT = 2;
+        if (p.TT > T) p.TT = T;
+        if ((p.TT * F) % 2) p.kind = 0;
+        p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
+        if (p.lds > 150 * 1024) p.kind = 0;
+    }
+    if (p.kind == 0) {
+        p.TT = 4;
+        if (p.TT > T) p.TT = T;
+        size_t a = (((size_t)(p.TT + 2) * (F + 2) + 3) & ~(size_t)3) * sizeof(float);
+        size_t red = (size_t)256 * 36 * sizeof(float);
+        p.lds = a + red;
+    }
+    p.tblocks = cdiv(T, p.TT);
+    p.ntiles = B * p.tblocks;
+    p.ngroups = p.ntiles < 128 ? p.ntiles : 128;
+    p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
+    return p;
+}
+
+extern "C" size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout) {
+    WgradPlan a = wgrad_plan(B, Cin, F, T, Cout, 0), b = wgrad_plan(B, Cin, F, T, Cout, 1);
+    size_t m = a.slab_floats > b.slab_floats ? a.slab_floats : b.slab_floats;
+    return m * sizeof(float);
+}
+
+// small: slabs [group][ci][9][Cout]
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    float* hp = smem;                               // [(TT+2)][F2] one input channel
+    float* red = smem + (((TT + 2) * F2 + 3) & ~3); // [nslots][9][Cout]
+    const int tid = threadIdx.x;
+    const int ncg = Cout >> 2, nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    for (int ci = 0; ci < Cin; ++ci) {
+        f32x4 acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = (f32x4){0, 0, 0, 0};
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+            __syncthreads();
+            for (int i = tid; i < (TT + 2) * F2; i += 256) {
+                int tt, ff;
+                if (x_nchw) { tt = i % (TT + 2); ff = i / (TT + 2); } else { ff = i % F2; tt = i / F2; }
+                int t = t0 + tt - 1, f = ff - 1;
+                float v = 0.f;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = x_nchw ? x[(((size_t)b * Cin + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * Cin + ci];
+                hp[tt * F2 + ff] = v;
+            }
+            __syncthreads();
+            if (active) {
+                for (int p = slot; p < TT * F; p += nslots) {
+                    int tl = p / F, f = p - tl * F;
+                    if (t0 + tl >= T) break;
+                    f32x4 d4 = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            acc[kh * 3 + kw] += hp[(tl + kw) * F2 + f + kh] * d4;
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *(f32x4*)(red + (slot * 9 + k) * Cout + cg * 4) = acc[k];
+        }
+        __syncthreads();
+        for (int i = tid; i < 9 * Cout; i += 256) {
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[s * 9 * Cout + i];
+            slabs[(((size_t)blockIdx.x * Cin + ci) * 9) * Cout + i] = a;
+        }
+    }
+}
+
+// small reduce: dw[co][ci][tap] = sum_g slabs[g][ci][tap][co]
+__global__ void conv_wgrad_reduce_small_k(const float* __restrict__ slabs, float* __restrict__ dw,
+                                          int ngroups, int Cin, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cin * 9 * Cout;
+    if (i >= n) return;
+    int co = i % Cout, tap = (i / Cout) % 9, ci = i / (9 * Cout);
+    float a = 0.f;
+    for (int g = 0; g < ngroups; ++g) a += slabs[(size_t)g * n + i];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = a;
+}
+
+// mfma: grid (ngroups, Cin/32, Cout/128); slabs [group][9][Cin][Cout]
+__global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    const int HR = (TT + 2) * F2;
+    float* xh = smem;                 // [HR][32]
+    float* dys = smem + HR * 32;      // [TT*F][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
+    const int MROWS = TT * F;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+        __syncthreads();
+        for (int i = tid; i < HR * 8; i += 256) {
+            int row = i >> 3, q = i & 7;
+            int tt = row / F2, ff = row - tt * F2;
+            int t = t0 + tt - 1, f = ff - 1;
+            f32x4 v = {0, 0, 0, 0};
+            if (t >= 0 && t < T && f >= 0 && f < F)
+                v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
+            *(f32x4*)(xh + row * 32 + q * 4) = v;
+        }
+        for (int i = tid; i < MROWS * 32; i += 256) {
+            int row = i >> 5, q = i & 31;
+            int tl = row / F, f = row - tl * F;
+            f32x4 v = {0, 0, 0, 0};
+            if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
+            *(f32x4*)(dys + row * 128 + q * 4) = v;
+        }
+        __syncthreads();
+        int tl = 0, f = h;            // position p = 2s + h
+        if (f >= F) { f -= F; tl = 1; }
+        for (int s = 0; s < MROWS / 2; ++s) {
+            const float* xp = xh + (tl * F2 + f) * 32 + r;
+            float bv = dys[(2 * s + h) * 128 + wave * 32 + r];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    float av = xp[(kw * F2 + kh) * 32];
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
+                }
+            f += 2;
+            if (f >= F) { f -= F; ++tl; }
+        }
+    }
+    // D rows = ci, cols = co
+    float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            sl[((size_t)k * Cin + ci0 + row) * Cout + co0 + wave * 32 + r] = acc[k][j];
+        }
+}
+
+// mfma reduce: dw[co][ci][tap] = sum_g slabs[g][tap][ci][co]
+__global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float* __restrict__ dw,
+                                         int ngroups, int Cin, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cin * 9 * Cout;
+    if (i >= n) return;
+    int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cin * Cout);
+    float a = 0.f;
+    for (int g = 0; g < ngroups; ++g) a += slabs[(size_t)g * n + i];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = a;
+}
+
+extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                                 int B, int Cin, int F, int T, int Cout, void* stream) {
+    SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
+    SED_REQUIRE(Cout % 4 == 0, "conv3x3_wgrad: Cout must be a multiple of 4 (got %d)", Cout);
+    WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw);
+    hipStream_t s = as_stream(stream);
+    float* slabs = (float*)workspace;
+    int n = Cin * 9 * Cout;
+    const double npos = (double)B * T * F;
+    SedProfScope prof(p.kind == 1 ? SED_K_CONV_MFMA_WGRAD : SED_K_CONV_SMALL_WGRAD, s,
+                      p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
+    if (p.kind == 1) {
+        SED_TRY(set_lds(conv3x3_mfma_wgrad_k, p.lds));
+        conv3x3_mfma_wgrad_k<<<dim3(p.ngroups, Cin / 32, Cout / 128), 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
+        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    } else {
+        SED_REQUIRE(256 % (Cout / 4) == 0 || Cout / 4 <= 256, "conv3x3_wgrad: unsupported Cout=%d", Cout);
+        SED_TRY(set_lds(conv3x3_small_wgrad_k, p.lds));
+        conv3x3_small_wgrad_k<<<p.ngroups, 256, p.lds, s>>>(x, x_is_nchw, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        SED_LAUNCH_CHECK("conv3x3_small_wgrad");
+        conv_wgrad_reduce_small_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    }
+    SED_LAUNCH_CHECK("conv3x3_wgrad_reduce");
+    return 0;
+}

@@ -1,0 +1,252 @@
+// gru.hip — the serial part of nn.GRU (reference sed.py:101-102,111; crnn_lightning.py:61-62,71).
+//
+// The input projections x W_ih^T + b_ih of all timesteps are one dense GEMM (gemm.hip).  What is left is
+// the recurrence: T' strictly serial steps of gh = h W_hh^T + b_hh followed by the gate math.  Per-step
+// kernel launches would cost more than the arithmetic, so each workgroup runs the whole time loop of
+// one (batch tile, direction) in-kernel: W_hh stays resident in registers (one gate row per thread,
+// H <= 128) or is streamed from L2 (larger H), h lives in LDS.  fp32 MFMA runs at the fp32 VALU rate on
+// gfx950, so the per-step matvec is plain v_fma with a small batch tile (more workgroups in flight)
+// rather than a 32-wide MFMA tile.
+//
+// PyTorch gate convention (r,z,n):  r = s(gi_r+gh_r)  z = s(gi_z+gh_z)  n = tanh(gi_n + r*gh_n)
+//                                   h' = (1-z)*n + z*h,  h0 = 0.
+#include "common.h"
+
+#define GRU_BT 4   // batch rows per workgroup
+
+__global__ void gru_pack_whh_t_k(const float* __restrict__ w0, const float* __restrict__ w1,
+                                 float* __restrict__ wt, int H) {
+    // wt[dir][k][g] = whh[dir][g][k]
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = 3 * H * H;
+    if (i >= 2 * n) return;
+    int dir = i / n, e = i - dir * n;
+    int g = e / H, k = e - g * H;
+    const float* w = dir ? w1 : w0;
+    wt[(size_t)dir * n + (size_t)k * 3 * H + g] = w[e];
+}
+
+constexpr int gru_nt(int hreg) { return hreg > 0 ? ((3 * hreg + 63) / 64) * 64 : 1024; }
+
+template <int HREG>
+__global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
+    const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
+    const float* __restrict__ bhh1, float* __restrict__ out, float* __restrict__ saved, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* h_s = smem;                    // [BT][H]
+    float* gh_s = smem + GRU_BT * H;      // [BT][3H]
+    const int g = threadIdx.x;
+    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BT;
+    const int H3 = 3 * H;
+    const float* wtd = wt + (size_t)dir * H3 * H;
+    const float* bhh = dir ? bhh1 : bhh0;
+    const bool row = g < H3;
+    const bool gate = g < H;
+
+    float wreg[HREG > 0 ? HREG : 1];
+    if (HREG > 0 && row) {
+#pragma unroll
+        for (int k = 0; k < HREG; ++k) wreg[k] = wtd[(size_t)k * H3 + g];
+    }
+    const float bias = row ? bhh[g] : 0.f;
+    for (int i = g; i < GRU_BT * H; i += blockDim.x) h_s[i] = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int tt = dir ? (T - 1 - s) : s;
+        // prefetch this step's input projections (gate threads) so the latency hides under the matvec
+        float gr[GRU_BT], gz[GRU_BT], gn[GRU_BT];
+        if (gate) {
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) {
+                int bg = b0 + b;
+                if (bg < B) {
+                    const float* p = gi + (((size_t)bg * T + tt) * 2 + dir) * H3;
+                    gr[b] = p[g]; gz[b] = p[H + g]; gn[b] = p[2 * H + g];
+                } else { gr[b] = gz[b] = gn[b] = 0.f; }
+            }
+        }
+        if (row) {
+            float acc[GRU_BT];
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) acc[b] = bias;
+            if (HREG > 0) {
+#pragma unroll
+                for (int k = 0; k < HREG; k += 4) {
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 hv = *(const f32x4*)(h_s + b * H + k);
+                        acc[b] += wreg[k] * hv[0] + wreg[k + 1] * hv[1] + wreg[k + 2] * hv[2] + wreg[k + 3] * hv[3];
+                    }
+                }
+            } else {
+                for (int k = 0; k < H; k += 4) {
+                    float w0 = wtd[(size_t)k * H3 + g], w1 = wtd[(size_t)(k + 1) * H3 + g];
+                    float w2 = wtd[(size_t)(k + 2) * H3 + g], w3 = wtd[(size_t)(k + 3) * H3 + g];
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 hv = *(const f32x4*)(h_s + b * H + k);
+                        acc[b] += w0 * hv[0] + w1 * hv[1] + w2 * hv[2] + w3 * hv[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) gh_s[b * H3 + g] = acc[b];
+        }
+        __syncthreads();
+        if (gate) {
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) {
+                int bg = b0 + b;
+                float ghr = gh_s[b * H3 + g], ghz = gh_s[b * H3 + H + g], ghn = gh_s[b * H3 + 2 * H + g];
+                float hp = h_s[b * H + g];
+                float r = 1.f / (1.f + expf(-(gr[b] + ghr)));
+                float z = 1.f / (1.f + expf(-(gz[b] + ghz)));
+                float n = tanhf(gn[b] + r * ghn);
+                float hn = (1.f - z) * n + z * hp;
+                h_s[b * H + g] = hn;
+                if (bg < B) {
+                    out[((size_t)bg * T + tt) * 2 * H + dir * H + g] = hn;
+                    if (saved) {
+                        float* sp = saved + ((((size_t)bg * T + tt) * 2 + dir) * 5) * H + g;
+                        sp[0] = r; sp[H] = z; sp[2 * H] = n; sp[3 * H] = ghn; sp[4 * H] = hp;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int HREG>
+__global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
+    const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ whh0,
+    const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, int B, int T, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H3 = 3 * H;
+    float* dgh_s = smem;                         // [BT][3H]
+    float* part_s = smem + GRU_BT * H3;          // [3][BT][H]
+    const int g = threadIdx.x;
+    const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BT;
+    const float* whh = dir ? whh1 : whh0;
+    const bool row = g < H3;
+    const bool gate = g < H;
+    const int p = g / H, k = g - p * H;          // thread (p,k): column k of gate block p
+
+    float wreg[HREG > 0 ? HREG : 1];
+    if (HREG > 0 && row) {
+#pragma unroll
+        for (int j = 0; j < HREG; ++j) wreg[j] = whh[((size_t)p * H + j) * H + k];
+    }
+    for (int i = g; i < 3 * GRU_BT * H; i += blockDim.x) part_s[i] = 0.f;
+    float dhc[GRU_BT];                           // direct part z*dh carried by the gate thread
+#pragma unroll
+    for (int b = 0; b < GRU_BT; ++b) dhc[b] = 0.f;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int tt = dir ? s : (T - 1 - s);    // reverse of the forward processing order
+        if (gate) {
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) {
+                int bg = b0 + b;
+                float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dghn = 0.f, carry = 0.f;
+                if (bg < B) {
+                    const float* sp = saved + ((((size_t)bg * T + tt) * 2 + dir) * 5) * H + g;
+                    float r = sp[0], z = sp[H], n = sp[2 * H], ghn = sp[3 * H], hp = sp[4 * H];
+                    float dh = dout[((size_t)bg * T + tt) * 2 * H + dir * H + g] + dhc[b] +
+                               part_s[(0 * GRU_BT + b) * H + g] + part_s[(1 * GRU_BT + b) * H + g] +
+                               part_s[(2 * GRU_BT + b) * H + g];
+                    float dn = dh * (1.f - z);
+                    float dz = dh * (hp - n);
+                    carry = dh * z;
+                    dn_pre = dn * (1.f - n * n);
+                    dz_pre = dz * z * (1.f - z);
+                    float dr = dn_pre * ghn;
+                    dghn = dn_pre * r;
+                    dr_pre = dr * r * (1.f - r);
+                    size_t o = (((size_t)bg * T + tt) * 2 + dir) * H3 + g;
+                    dgi[o] = dr_pre; dgi[o + H] = dz_pre; dgi[o + 2 * H] = dn_pre;
+                    dgh[o] = dr_pre; dgh[o + H] = dz_pre; dgh[o + 2 * H] = dghn;
+                }
+                dhc[b] = carry;
+                dgh_s[b * H3 + g] = dr_pre; dgh_s[b * H3 + H + g] = dz_pre; dgh_s[b * H3 + 2 * H + g] = dghn;
+            }
+        }
+        __syncthreads();
+        if (row) {
+            float acc[GRU_BT];
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) acc[b] = 0.f;
+            if (HREG > 0) {
+#pragma unroll
+                for (int j = 0; j < HREG; j += 4) {
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 dv = *(const f32x4*)(dgh_s + b * H3 + p * H + j);
+                        acc[b] += wreg[j] * dv[0] + wreg[j + 1] * dv[1] + wreg[j + 2] * dv[2] + wreg[j + 3] * dv[3];
+                    }
+                }
+            } else {
+                for (int j = 0; j < H; j += 4) {
+                    const float* wp = whh + ((size_t)p * H + j) * H + k;
+                    float w0 = wp[0], w1 = wp[H], w2 = wp[2 * H], w3 = wp[3 * H];
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 dv = *(const f32x4*)(dgh_s + b * H3 + p * H + j);
+                        acc[b] += w0 * dv[0] + w1 * dv[1] + w2 * dv[2] + w3 * dv[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < GRU_BT; ++b) part_s[(p * GRU_BT + b) * H + k] = acc[b];
+        }
+        __syncthreads();
+    }
+}
+
+static int gru_threads(int H) { return ((3 * H + 63) / 64) * 64; }
+
+extern "C" size_t sed_gru_seq_workspace_bytes(int H) { return (size_t)2 * 3 * H * H * sizeof(float); }
+
+#define GRU_DISPATCH(KERNEL, ...)                                                             \
+    switch (H) {                                                                              \
+        case 8: KERNEL<8><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                          \
+        case 16: KERNEL<16><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
+        case 32: KERNEL<32><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
+        case 64: KERNEL<64><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
+        case 128: KERNEL<128><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                      \
+        default: KERNEL<0><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                         \
+    }
+
+extern "C" int sed_gru_seq_fwd(const float* gi, const float* const* whh, const float* const* bhh, float* out,
+                               float* saved, void* workspace, int B, int T, int H, void* stream) {
+    SED_REQUIRE(gi && whh && bhh && out && workspace && whh[0] && whh[1] && bhh[0] && bhh[1], "gru_seq_fwd: null pointer");
+    SED_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && 3 * H <= 1024, "gru_seq_fwd: H=%d must be a multiple of 4 and <= 341", H);
+    hipStream_t s = as_stream(stream);
+    float* wt = (float*)workspace;
+    int n = 2 * 3 * H * H;
+    gru_pack_whh_t_k<<<cdiv(n, 256), 256, 0, s>>>(whh[0], whh[1], wt, H);
+    SED_LAUNCH_CHECK("gru_pack_whh_t");
+    dim3 grid(cdiv(B, GRU_BT), 2);
+    int nt = gru_threads(H);
+    size_t lds = (size_t)GRU_BT * 4 * H * sizeof(float);
+    SedProfScope prof(SED_K_GRU_FWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
+    GRU_DISPATCH(gru_seq_fwd_k, gi, wt, bhh[0], bhh[1], out, saved, B, T, H);
+    SED_LAUNCH_CHECK("gru_seq_fwd");
+    return 0;
+}
+
+extern "C" int sed_gru_seq_bwd(const float* dout, const float* saved, const float* const* whh, float* dgi,
+                               float* dgh, int B, int T, int H, void* stream) {
+    SED_REQUIRE(dout && saved && whh && whh[0] && whh[1] && dgi && dgh, "gru_seq_bwd: null pointer");
+    SED_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && 3 * H <= 1024, "gru_seq_bwd: H=%d must be a multiple of 4 and <= 341", H);
+    hipStream_t s = as_stream(stream);
+    dim3 grid(cdiv(B, GRU_BT), 2);
+    int nt = gru_threads(H);
+    size_t lds = (size_t)GRU_BT * 6 * H * sizeof(float);
+    SedProfScope prof(SED_K_GRU_BWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
+    GRU_DISPATCH(gru_seq_bwd_k, dout, saved, whh[0], whh[1], dgi, dgh, B, T, H);
+    SED_LAUNCH_CHECK("gru_seq_bwd");
+    return 0;
+}

@@ -1,0 +1,262 @@
+// net.hip — the whole-network plan: TimePooledCRNN.forward (reference sed.py:105-112,
+// crnn_lightning.py:66-73) and its backward as a fixed sequence of launches on one stream.
+//
+// No host synchronisation, no allocation: every intermediate lives in the caller's workspace at
+// offsets that are a pure function of the config, so a step is capturable in a hipGraph and the
+// backward can be issued in stages (head+GRU, conv3, conv2, conv1) to overlap the RCCL all-reduce.
+#include <string.h>
+#include "common.h"
+
+namespace {
+
+struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw; float drop; };
+struct GruL { int in, H; };
+
+struct Layout {
+    int n_conv, n_gru, n_dense, M, Tp, Fp, feat;
+    ConvL cv[SED_MAX_CONV];
+    GruL gr[SED_MAX_GRU];
+    int dK[SED_MAX_DENSE], dN[SED_MAX_DENSE];
+    // float offsets into the workspace
+    size_t wp_f[SED_MAX_CONV], wp_d[SED_MAX_CONV], conv_out[SED_MAX_CONV], stat[SED_MAX_CONV];
+    size_t mean[SED_MAX_CONV], rstd[SED_MAX_CONV], scale[SED_MAX_CONV], shift[SED_MAX_CONV];
+    size_t pooled[SED_MAX_CONV];
+    size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
+    size_t act[SED_MAX_DENSE];
+    // backward only
+    size_t bn_part, sum_g, sum_gx, dbias_part, dconv, gradA, wgrad_ws, dgi, dgh, dgout[SED_MAX_GRU];
+    size_t dact[SED_MAX_DENSE], lin_ws;
+    size_t total;     // floats
+};
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t n) { size_t o = off; off += (n + 63) & ~(size_t)63; return o; }   // 256-byte granules
+};
+
+int build_layout(const sed_net_cfg* c, int training, Layout* L) {
+    SED_REQUIRE(c, "net: null config");
+    SED_REQUIRE(c->B > 0 && c->Cin > 0 && c->F > 0 && c->T > 0, "net: bad input shape B=%d Cin=%d F=%d T=%d", c->B, c->Cin, c->F, c->T);
+    SED_REQUIRE(c->n_conv >= 1 && c->n_conv <= SED_MAX_CONV, "net: n_conv=%d out of range", c->n_conv);
+    SED_REQUIRE(c->n_gru >= 1 && c->n_gru <= SED_MAX_GRU, "net: n_gru=%d out of range", c->n_gru);
+    SED_REQUIRE(c->n_dense >= 1 && c->n_dense <= SED_MAX_DENSE, "net: n_dense=%d out of range", c->n_dense);
+    memset(L, 0, sizeof(*L));
+    L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
+    Carver cv;
+    int Cin = c->Cin, T = c->T, F = c->F;
+    size_t max_conv = 0, max_pool = 0, max_wgrad = 0;
+    int max_bn_rows = 0, maxC = 0;
+    for (int l = 0; l < c->n_conv; ++l) {
+        ConvL& q = L->cv[l];
+        q.Cin = Cin; q.C = c->C[l]; q.T = T; q.F = F; q.pf = c->pool_f[l]; q.pt = c->pool_t[l];
+        q.drop = c->drop_p[l]; q.nchw = (l == 0);
+        SED_REQUIRE(q.C > 0 && q.C % 4 == 0, "net: conv channels C[%d]=%d must be a positive multiple of 4", l, q.C);
+        SED_REQUIRE(q.pf >= 1 && q.pt >= 1 && T % q.pt == 0 && F % q.pf == 0,
+                    "net: block %d: T=%d/F=%d not divisible by pool (%d,%d)", l, T, F, q.pt, q.pf);
+        SED_REQUIRE(q.drop >= 0.f && q.drop < 1.f, "net: drop_p[%d]=%f out of [0,1)", l, q.drop);
+        q.Tp = T / q.pt; q.Fp = F / q.pf;
+        q.rows = sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
+        SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
+        q.bn_rows = sed_bn_bwd_rows(c->B, q.T, q.pt);
+        size_t nout = (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
+        L->wp_f[l] = cv.take((size_t)9 * q.C * q.Cin);
+        L->wp_d[l] = cv.take((size_t)9 * q.C * q.Cin);
+        L->conv_out[l] = cv.take(nout);
+        L->stat[l] = cv.take((size_t)q.rows * 2 * q.C);
+        L->mean[l] = cv.take(q.C); L->rstd[l] = cv.take(q.C); L->scale[l] = cv.take(q.C); L->shift[l] = cv.take(q.C);
+        L->pooled[l] = cv.take(npool);
+        if (nout > max_conv) max_conv = nout;
+        if (npool > max_pool) max_pool = npool;
+        size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
+        if (wg > max_wgrad) max_wgrad = wg;
+        if (q.bn_rows > max_bn_rows) max_bn_rows = q.bn_rows;
+        if (q.C > maxC) maxC = q.C;
+        Cin = q.C; T = q.Tp; F = q.Fp;
+    }
+    L->Tp = T; L->Fp = F; L->feat = Cin * F; L->M = c->B * T;
+    const size_t M = (size_t)L->M;
+    int in = L->feat, maxH = 0, max2H = 0;
+    for (int i = 0; i < c->n_gru; ++i) {
+        int H = c->H[i];
+        SED_REQUIRE(H > 0 && H % 4 == 0 && 3 * H <= 1024, "net: GRU hidden H[%d]=%d must be a multiple of 4 and <= 341", i, H);
+        L->gr[i].in = in; L->gr[i].H = H;
+        L->gi[i] = cv.take(M * 6 * H);
+        L->gout[i] = cv.take(M * 2 * H);
+        L->saved[i] = training ? cv.take(M * 10 * H) : 0;
+        if (H > maxH) maxH = H;
+        in = 2 * H;
+        if (in > max2H) max2H = in;
+    }
+    L->gru_ws = cv.take((size_t)6 * maxH * maxH);
+    size_t max_lin_ws = 0;
+    for (int j = 0; j < c->n_dense; ++j) {
+        SED_REQUIRE(c->D[j] > 0, "net: dense size D[%d]=%d", j, c->D[j]);
+        L->dK[j] = in; L->dN[j] = c->D[j];
+        L->act[j] = (j < c->n_dense - 1) ? cv.take(M * c->D[j]) : 0;
+        size_t w = sed_linear_bwd_workspace_bytes(L->M, in, c->D[j]) / sizeof(float);
+        if (w > max_lin_ws) max_lin_ws = w;
+        in = c->D[j];
+    }
+    if (training) {
+        L->bn_part = cv.take((size_t)max_bn_rows * 2 * maxC);
+        L->sum_g = cv.take(maxC); L->sum_gx = cv.take(maxC);
+        L->dbias_part = cv.take((size_t)max_bn_rows * maxC);
+        L->dconv = cv.take(max_conv);
+        size_t ga = max_pool > M * (size_t)L->feat ? max_pool : M * (size_t)L->feat;
+        L->gradA = cv.take(ga);
+        L->wgrad_ws = cv.take(max_wgrad);
+        L->dgi = cv.take(M * 6 * maxH);
+        L->dgh = cv.take(M * 6 * maxH);
+        for (int i = 0; i < c->n_gru; ++i) L->dgout[i] = cv.take(M * 2 * c->H[i]);
+        for (int j = 0; j < c->n_dense - 1; ++j) L->dact[j] = cv.take(M * c->D[j]);
+        L->lin_ws = cv.take(max_lin_ws);
+    }
+    L->total = cv.off;
+    return 0;
+}
+
+inline uint64_t layer_seed(uint64_t seed, int l) { return seed + 0x9E3779B97F4A7C15ull * (uint64_t)(l + 1); }
+
+}  // namespace
+
+extern "C" int sed_net_out_shape(const sed_net_cfg* cfg, int* Tp, int* Fp) {
+    Layout L;
+    SED_TRY(build_layout(cfg, 0, &L));
+    if (Tp) *Tp = L.Tp;
+    if (Fp) *Fp = L.Fp;
+    return 0;
+}
+
+extern "C" size_t sed_net_workspace_bytes(const sed_net_cfg* cfg, int training) {
+    Layout L;
+    if (build_layout(cfg, training, &L) != 0) return 0;
+    return L.total * sizeof(float);
+}
+
+extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
+                               void* workspace, int training, uint64_t seed, void* stream) {
+    SED_REQUIRE(p && x && logits && workspace, "net_forward: null pointer");
+    Layout L;
+    SED_TRY(build_layout(c, training, &L));
+    float* ws = (float*)workspace;
+    const int B = c->B;
+    const float* in = x;
+    for (int l = 0; l < L.n_conv; ++l) {
+        const ConvL& q = L.cv[l];
+        SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
+                    "net_forward: missing parameters of conv block %d", l);
+        SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
+                                         q.C, q.Cin, stream));
+        SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
+                                training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+        if (training)
+            SED_TRY(sed_bn_finalize_train(ws + L.stat[l], q.rows, q.C, (double)B * q.T * q.F, p->bn_g[l], p->bn_b[l],
+                                          p->bn_rm[l], p->bn_rv[l], c->bn_momentum, c->bn_eps, ws + L.mean[l],
+                                          ws + L.rstd[l], ws + L.scale[l], ws + L.shift[l], stream));
+        else
+            SED_TRY(sed_bn_finalize_eval(p->bn_g[l], p->bn_b[l], p->bn_rm[l], p->bn_rv[l], c->bn_eps, q.C,
+                                         ws + L.scale[l], ws + L.shift[l], stream));
+        const int last = (l == L.n_conv - 1);
+        SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
+                                          q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
+                                          layer_seed(seed, l), stream));
+        in = ws + L.pooled[l];
+    }
+    const int M = L.M;
+    const float* gin = ws + L.pooled[L.n_conv - 1];          // [M][C*F'] in the reference feature order
+    for (int i = 0; i < L.n_gru; ++i) {
+        const int H = L.gr[i].H, K = L.gr[i].in;
+        for (int d = 0; d < 2; ++d) {
+            SED_REQUIRE(p->gru_wih[i][d] && p->gru_whh[i][d] && p->gru_bih[i][d] && p->gru_bhh[i][d],
+                        "net_forward: missing parameters of GRU layer %d dir %d", i, d);
+            SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
+                                 p->gru_bih[i][d], 0.f, M, 3 * H, K, stream));
+        }
+        const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
+        const float* bhh[2] = {p->gru_bhh[i][0], p->gru_bhh[i][1]};
+        SED_TRY(sed_gru_seq_fwd(ws + L.gi[i], whh, bhh, ws + L.gout[i], training ? ws + L.saved[i] : nullptr,
+                                ws + L.gru_ws, B, L.Tp, H, stream));
+        gin = ws + L.gout[i];
+    }
+    const float* din = gin;
+    for (int j = 0; j < L.n_dense; ++j) {
+        SED_REQUIRE(p->dense_w[j] && p->dense_b[j], "net_forward: missing parameters of dense layer %d", j);
+        const int last = (j == L.n_dense - 1);
+        float* y = last ? logits : ws + L.act[j];
+        SED_TRY(sed_linear_fwd(din, p->dense_w[j], p->dense_b[j], y, M, L.dK[j], L.dN[j], !last, stream));
+        din = y;
+    }
+    return 0;
+}
+
+extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
+                                const float* x, const float* dlogits, void* workspace, uint64_t seed,
+                                int stage_begin, int stage_end, void* stream) {
+    SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward: null pointer");
+    Layout L;
+    SED_TRY(build_layout(c, 1, &L));
+    SED_REQUIRE(stage_begin >= 0 && stage_end <= L.n_conv + 1 && stage_begin < stage_end,
+                "net_backward: bad stage range [%d,%d)", stage_begin, stage_end);
+    float* ws = (float*)workspace;
+    const int B = c->B, M = L.M;
+
+    if (stage_begin == 0) {
+        // ── dense head ──
+        const float* gru_last = ws + L.gout[L.n_gru - 1];
+        for (int j = L.n_dense - 1; j >= 0; --j) {
+            const int last = (j == L.n_dense - 1);
+            const float* xin = (j == 0) ? gru_last : ws + L.act[j - 1];
+            float* dy = last ? const_cast<float*>(dlogits) : ws + L.dact[j];   // relu=0 on the last layer: not modified
+            float* dx = (j == 0) ? ws + L.dgout[L.n_gru - 1] : ws + L.dact[j - 1];
+            SED_REQUIRE(g->dense_w[j] && g->dense_b[j], "net_backward: missing gradient buffers of dense layer %d", j);
+            SED_TRY(sed_linear_bwd(xin, p->dense_w[j], last ? nullptr : ws + L.act[j], dy, dx, g->dense_w[j],
+                                   g->dense_b[j], ws + L.lin_ws, M, L.dK[j], L.dN[j], !last, stream));
+        }
+        // ── GRU stack ──
+        for (int i = L.n_gru - 1; i >= 0; --i) {
+            const int H = L.gr[i].H, K = L.gr[i].in;
+            const float* xin = (i == 0) ? ws + L.pooled[L.n_conv - 1] : ws + L.gout[i - 1];
+            float* dxin = (i == 0) ? ws + L.gradA : ws + L.dgout[i - 1];
+            const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
+            float* dgi = ws + L.dgi;
+            float* dgh = ws + L.dgh;
+            SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, B, L.Tp, H, stream));
+            for (int d = 0; d < 2; ++d) {
+                SED_REQUIRE(g->gru_wih[i][d] && g->gru_whh[i][d] && g->gru_bih[i][d] && g->gru_bhh[i][d],
+                            "net_backward: missing gradient buffers of GRU layer %d dir %d", i, d);
+                // dW_hh = dgh^T h_prev ; dW_ih = dgi^T x
+                SED_TRY(sed_gemm_f32(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
+                                     g->gru_whh[i][d], H, nullptr, 0.f, 3 * H, H, M, stream));
+                SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
+                SED_TRY(sed_reduce_rows(dgh + d * 3 * H, M, 3 * H, 6 * H, g->gru_bhh[i][d], stream));
+                SED_TRY(sed_reduce_rows(dgi + d * 3 * H, M, 3 * H, 6 * H, g->gru_bih[i][d], stream));
+                // dx += dgi W_ih
+                SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 6 * H, 1, p->gru_wih[i][d], K, 1, dxin, K, nullptr, d ? 1.f : 0.f,
+                                     M, K, 3 * H, stream));
+            }
+        }
+    }
+    // ── conv blocks, last to first ──
+    for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
+        const int l = L.n_conv - s;
+        const ConvL& q = L.cv[l];
+        const int last = (l == L.n_conv - 1);
+        const float drop = q.drop;
+        const uint64_t sd = layer_seed(seed, l);
+        SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
+        const float* y = ws + L.conv_out[l];
+        SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
+                                                 ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last,
+                                                 drop, sd, stream));
+        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], stream));
+        SED_TRY(sed_bn_relu_pool_drop_bwd_apply(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
+                                                ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, ws + L.dconv,
+                                                ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, drop, sd, stream));
+        SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], stream));
+        const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
+        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv, g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
+        if (l > 0)   // data gradient = the same convolution with flipped, transposed taps
+            SED_TRY(sed_conv3x3_fwd(ws + L.dconv, 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+    }
+    return 0;
+}

@@ -1,0 +1,62 @@
+"""Log-mel front end on the GPU: ``_mbe`` of reference feature.py:55-59 as one HIP kernel.
+
+``mbe(y)`` = log(mel_basis @ |STFT(y, n_fft=2048, hop=1024)|^2).T with librosa's defaults (periodic Hann,
+center=True, Slaney mel scale and area normalisation, fmin 0, fmax sr/2).  librosa changed its STFT
+edge padding from 'reflect' to 'constant' in 0.10, so ``pad_mode`` is explicit.  The constant tables
+(window, FFT twiddles, mel basis) are computed once on the host in float64 and cached per device.
+feature.py:127-129's StandardScaler can be fused in through ``mean``/``std``.
+"""
+import functools
+
+import numpy as np
+import torch
+
+from ._lib import check, lib, ptr, stream_ptr
+
+SR, NFFT, HOP, NB_MEL = 44_100, 2048, 1024, 40        # reference feature.py:29-32
+
+
+def slaney_mel_basis(sr=SR, n_fft=NFFT, n_mels=NB_MEL):
+    """librosa.filters.mel(sr, n_fft, n_mels) with its defaults (htk=False, norm='slaney')."""
+    f_sp, brk = 200.0 / 3.0, 1000.0
+    brk_mel, step = brk / f_sp, np.log(6.4) / 27.0
+
+    def to_mel(f):
+        return np.where(f >= brk, brk_mel + np.log(np.maximum(f, brk) / brk) / step, f / f_sp)
+
+    def to_hz(m):
+        return np.where(m >= brk_mel, brk * np.exp(step * (m - brk_mel)), f_sp * m)
+    edges = to_hz(np.linspace(to_mel(np.float64(0.0)), to_mel(np.float64(sr / 2.0)), n_mels + 2))
+    bins = np.arange(n_fft // 2 + 1, dtype=np.float64) * (sr / n_fft)
+    lo, ce, hi = edges[:-2, None], edges[1:-1, None], edges[2:, None]
+    tri = np.minimum((bins[None, :] - lo) / (ce - lo), (hi - bins[None, :]) / (hi - ce))
+    tri = np.maximum(tri, 0.0) * (2.0 / (hi - lo))
+    return tri.astype(np.float32)
+
+
+@functools.lru_cache(maxsize=8)
+def _tables(device_index, sr, n_fft, n_mels):
+    dev = torch.device("cuda", device_index)
+    n = np.arange(n_fft, dtype=np.float64)
+    window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).astype(np.float32)
+    k = np.arange(n_fft // 2, dtype=np.float64)
+    tw = np.stack([np.cos(2.0 * np.pi * k / n_fft), -np.sin(2.0 * np.pi * k / n_fft)], axis=1).astype(np.float32)
+    fb = slaney_mel_basis(sr, n_fft, n_mels)
+    return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (window, tw, fb))
+
+
+def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=None, std=None):
+    """y: mono float32 PCM CUDA tensor [N] -> [1 + N//hop, n_mels] log-mel energies (natural log, no eps)."""
+    if not (isinstance(y, torch.Tensor) and y.is_cuda):
+        raise RuntimeError("sed_crnn_amd.feature.mbe needs a CUDA(HIP) tensor; there is no CPU fallback")
+    y = y.contiguous().float()
+    window, tw, fb = _tables(y.device.index or 0, sr, n_fft, n_mels)
+    frames = 1 + y.numel() // hop
+    out = torch.empty(frames, n_mels, device=y.device)
+    inv = None
+    if mean is not None:
+        mean = mean.to(y.device).float().contiguous()
+        inv = (1.0 / std.to(y.device).float()).contiguous()
+    check(lib().sed_logmel(ptr(y), y.numel(), ptr(window), ptr(tw), ptr(fb), ptr(mean), ptr(inv), ptr(out), n_fft, hop,
+                           n_mels, {"constant": 0, "reflect": 1}[pad_mode], stream_ptr()), "sed_logmel")
+    return out

@@ -1,0 +1,72 @@
+"""Segment-based F1 / error-rate, API-compatible with reference metrics.py:20-74 (+ utils.py:4,11-12).
+
+Per-epoch host-side integer work in the reference too (sed.py:175-176; crnn_lightning.py:123-126), so it
+stays numpy here; written block-vectorised instead of the reference's Python loop over blocks.  Quirks
+kept on purpose: blocks straddle window boundaries, F1 keeps the partial last block
+(ceil) while ER drops it (floor), ER has no zero-reference guard.
+"""
+import numpy as np
+
+eps = np.finfo(float).eps
+
+
+def reshape_3Dto2D(A):
+    return A.reshape(A.shape[0] * A.shape[1], A.shape[2])
+
+
+def _prep(O, T):
+    O, T = np.asarray(O), np.asarray(T)
+    if O.ndim == 3:
+        O, T = reshape_3Dto2D(O), reshape_3Dto2D(T)
+    if O.dtype == bool:
+        O = O.astype(np.uint8)
+    if T.dtype == bool:
+        T = T.astype(np.uint8)
+    return O, T
+
+
+def f1_overall_framewise(O, T):
+    O, T = _prep(O, T)
+    TP = float(((2 * T - O) == 1).sum())
+    Nref, Nsys = float(T.sum()), float(O.sum())
+    prec = TP / (Nsys + eps)
+    recall = TP / (Nref + eps)
+    return 2 * prec * recall / (prec + recall + eps)
+
+
+def er_overall_framewise(O, T):
+    O, T = _prep(O, T)
+    FP = np.logical_and(T == 0, O == 1).sum(1)
+    FN = np.logical_and(T == 1, O == 0).sum(1)
+    S = np.minimum(FP, FN).sum()
+    D = np.maximum(0, FN - FP).sum()
+    I = np.maximum(0, FP - FN).sum()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (S + D + I) / (T.sum() + 0.0)
+
+
+def _blocks(A, block, n):
+    """max over consecutive row blocks; n blocks (a partial last block is padded with the identity 0)."""
+    rows = n * block
+    K = A.shape[1]
+    buf = np.zeros((rows, K), dtype=np.float64)
+    m = min(rows, A.shape[0])
+    buf[:m] = A[:m]
+    return buf.reshape(n, block, K).max(axis=1) if n else np.zeros((0, K))
+
+
+def f1_overall_1sec(O, T, block_size):
+    O, T = _prep(O, T)
+    n = int(np.ceil(O.shape[0] / block_size))
+    return f1_overall_framewise(_blocks(O, block_size, n), _blocks(T, block_size, n))
+
+
+def er_overall_1sec(O, T, block_size):
+    O, T = _prep(O, T)
+    n = int(O.shape[0] / block_size)
+    return er_overall_framewise(_blocks(O, block_size, n), _blocks(T, block_size, n))
+
+
+def compute_scores(pred, y, frames_in_1_sec=50):
+    return {"f1_overall_1sec": f1_overall_1sec(pred, y, frames_in_1_sec),
+            "er_overall_1sec": er_overall_1sec(pred, y, frames_in_1_sec)}

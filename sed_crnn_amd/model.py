@@ -1,0 +1,484 @@
+"""Host-side mirror of the reference model API, executing on libsedcrnn.so (HIP, gfx950).
+
+Mirrors
+  * ``TimePooledCRNN(conv_channels=128, dropout=0.5)``      reference sed.py:82-112
+  * ``LightningTimePooledCRNN(dropout=0.4)``                 reference crnn_lightning.py:41-73
+  * ``get_model(...)``                                        named at reference README.md:44
+with identical submodule / state_dict key names, shapes and initialisers, so reference checkpoints
+(``best_fold{n}.pt``, sed.py:198-199) load unchanged.  The submodules are parameter holders only: no
+torch.nn compute op is ever called; forward/backward go through one autograd.Function over the
+whole-network plan (sed_net_forward / sed_net_backward).  There is no CPU or torch fallback: without
+the HIP library or a GPU tensor the call raises.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import NetCfg, NetParams, check, lib
+
+_MASK64 = (1 << 64) - 1
+
+
+# ───────────────────────── parameter holders (same names / init as torch.nn) ─────────────────────────
+class ConvParams(nn.Module):
+    """nn.Conv2d(cin, cout, 3, padding=1) parameters: weight [cout,cin,3,3], bias [cout]."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(cin * 9)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size=(3, 3), padding=(1, 1) [HIP]"
+
+
+class BNParams(nn.Module):
+    """nn.BatchNorm2d(c) parameters and running statistics."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum} [HIP]"
+
+
+class GRUParams(nn.Module):
+    """nn.GRU(input_size, hidden_size, num_layers, batch_first=True, bidirectional=True) parameters."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        stdv = 1.0 / math.sqrt(hidden_size)
+        for k in range(num_layers):
+            isz = input_size if k == 0 else 2 * hidden_size
+            for sfx in ("", "_reverse"):
+                for name, shape in ((f"weight_ih_l{k}{sfx}", (3 * hidden_size, isz)),
+                                    (f"weight_hh_l{k}{sfx}", (3 * hidden_size, hidden_size)),
+                                    (f"bias_ih_l{k}{sfx}", (3 * hidden_size,)),
+                                    (f"bias_hh_l{k}{sfx}", (3 * hidden_size,))):
+                    p = nn.Parameter(torch.empty(*shape))
+                    nn.init.uniform_(p, -stdv, stdv)
+                    self.register_parameter(name, p)
+
+    def layer(self, k, d):
+        sfx = "_reverse" if d else ""
+        return tuple(getattr(self, f"{n}_l{k}{sfx}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+
+    def extra_repr(self):
+        return f"{self.input_size}, {self.hidden_size}, num_layers={self.num_layers}, bidirectional=True [HIP]"
+
+
+class LinearParams(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(fin)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features} [HIP]"
+
+
+# ───────────────────────── autograd bridge ─────────────────────────
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        logits = net._run_forward(x, training=True)
+        ctx.net, ctx.ticket, ctx.nparams = net, net._ticket, len(params)
+        ctx.save_for_backward(x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net = ctx.net
+        if ctx.ticket != net._ticket:
+            raise RuntimeError("sed_crnn_amd: the activations of this forward were overwritten by a later "
+                               "training forward of the same module; call backward() before the next forward()")
+        (x,) = ctx.saved_tensors
+        net._run_backward(x, dlogits.contiguous())
+        accumulate = any(p.grad is not None for p in net._arena_params)
+        grads = [g.clone() if accumulate else g for g in net._grad_views]
+        return (None, None) + tuple(grads)
+
+
+class HipCRNN(nn.Module):
+    """Base class: holds the architecture spec, the flat parameter/gradient arenas and the workspace."""
+
+    def _init_spec(self, *, in_channels, n_mels, conv_channels, pools, drops, gru_hidden, dense, bn_eps=1e-5,
+                   bn_momentum=0.1):
+        assert len(conv_channels) == len(pools) == len(drops) <= _lib.SED_MAX_CONV
+        assert 1 <= len(gru_hidden) <= _lib.SED_MAX_GRU and 1 <= len(dense) <= _lib.SED_MAX_DENSE
+        self.in_channels, self.n_mels = in_channels, n_mels
+        self.conv_channels = list(conv_channels)
+        self.pools = [tuple(p) for p in pools]          # (pool_f, pool_t) per block
+        self.drops = list(drops)
+        self.gru_hidden, self.dense = list(gru_hidden), list(dense)
+        self.bn_eps, self.bn_momentum = bn_eps, bn_momentum
+        f = n_mels
+        for pf, _ in self.pools:
+            f //= pf
+        self.flat_features = conv_channels[-1] * f
+        self.time_factor = math.prod(pt for _, pt in self.pools)
+        self._ticket = 0
+        self._seed_counter = 0
+        self._nbt_pending = 0
+        self._ws = {}
+        self._structs = None
+        self._arena = None
+
+    # subclasses return {role: tensor}; roles: conv_w/conv_b/bn_g/bn_b/bn_rm/bn_rv [l], gru_* [i][d], dense_* [j]
+    def _roles(self):
+        raise NotImplementedError
+
+    # ── flat arenas (backward-completion order: head+GRU, then conv blocks last -> first) ──
+    def _flatten(self):
+        r = self._roles()
+        order = []
+        for j in range(len(self.dense)):
+            order += [r["dense_w"][j], r["dense_b"][j]]
+        for i in range(len(self.gru_hidden)):
+            for d in range(2):
+                order += [r["gru_wih"][i][d], r["gru_whh"][i][d], r["gru_bih"][i][d], r["gru_bhh"][i][d]]
+        stage_ends = []
+        off = 0
+        offs = []
+        nconv = len(self.conv_channels)
+
+        def place(ps):
+            nonlocal off
+            for p in ps:
+                offs.append(off)
+                off += (p.numel() + 3) // 4 * 4
+        place(order)
+        stage_ends.append(off)
+        for l in range(nconv - 1, -1, -1):
+            ps = [r["conv_w"][l], r["conv_b"][l], r["bn_g"][l], r["bn_b"][l]]
+            order += ps
+            place(ps)
+            stage_ends.append(off)
+        dev = order[0].device
+        flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
+        views = []
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                n = p.numel()
+                flat[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = flat[o:o + n].view(p.shape)
+                views.append(flat_g[o:o + n].view(p.shape))
+                p.grad = None
+        assert len(order) == len(list(self.parameters())), "every parameter must have a role"
+        self._arena, self._arena_grad = flat, flat_g
+        self._arena_params, self._grad_views, self._arena_offsets = order, views, offs
+        self._stage_ends = stage_ends          # arena slice [stage_ends[s-1], stage_ends[s]) = backward stage s
+        self._structs = None
+        self._ws = {}
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        if hasattr(self, "_arena_params"):          # parameters were moved one by one: rebuild the arenas
+            self._flatten()
+        return self
+
+    def flat_parameters(self):
+        return self._arena
+
+    def flat_grads(self):
+        return self._arena_grad
+
+    def bucket_slices(self):
+        """Arena slices in backward-completion order, one per backward stage."""
+        b = [0] + self._stage_ends
+        return [(b[i], b[i + 1]) for i in range(len(b) - 1)]
+
+    def bind_flat_grads(self):
+        """Point every p.grad at its arena view (what the fused optimiser / all-reduce operate on)."""
+        for p, g in zip(self._arena_params, self._grad_views):
+            p.grad = g
+
+    # ── C structs ──
+    def _cfg(self, B, T):
+        c = NetCfg()
+        c.B, c.Cin, c.F, c.T = B, self.in_channels, self.n_mels, T
+        c.n_conv = len(self.conv_channels)
+        for l, ch in enumerate(self.conv_channels):
+            c.C[l] = ch
+            c.pool_f[l], c.pool_t[l] = self.pools[l]
+            c.drop_p[l] = float(self.drops[l])
+        c.n_gru = len(self.gru_hidden)
+        for i, h in enumerate(self.gru_hidden):
+            c.H[i] = h
+        c.n_dense = len(self.dense)
+        for j, d in enumerate(self.dense):
+            c.D[j] = d
+        c.bn_eps, c.bn_momentum = self.bn_eps, self.bn_momentum
+        return c
+
+    def _param_structs(self):
+        if self._structs is None:
+            r = self._roles()
+            gmap = {id(p): g for p, g in zip(self._arena_params, self._grad_views)}
+            P, G = NetParams(), NetParams()
+
+            def put(field, idx, t, grad=True):
+                tgt_p, tgt_g = getattr(P, field), getattr(G, field)
+                if isinstance(idx, tuple):
+                    tgt_p[idx[0]][idx[1]] = t.data_ptr()
+                    tgt_g[idx[0]][idx[1]] = gmap[id(t)].data_ptr() if grad else None
+                else:
+                    tgt_p[idx] = t.data_ptr()
+                    tgt_g[idx] = gmap[id(t)].data_ptr() if grad else None
+            for l in range(len(self.conv_channels)):
+                put("conv_w", l, r["conv_w"][l]); put("conv_b", l, r["conv_b"][l])
+                put("bn_g", l, r["bn_g"][l]); put("bn_b", l, r["bn_b"][l])
+                put("bn_rm", l, r["bn_rm"][l], grad=False); put("bn_rv", l, r["bn_rv"][l], grad=False)
+            for i in range(len(self.gru_hidden)):
+                for d in range(2):
+                    put("gru_wih", (i, d), r["gru_wih"][i][d]); put("gru_whh", (i, d), r["gru_whh"][i][d])
+                    put("gru_bih", (i, d), r["gru_bih"][i][d]); put("gru_bhh", (i, d), r["gru_bhh"][i][d])
+            for j in range(len(self.dense)):
+                put("dense_w", j, r["dense_w"][j]); put("dense_b", j, r["dense_b"][j])
+            self._structs = (P, G)
+        return self._structs
+
+    def _workspace(self, cfg, training):
+        key = (cfg.B, cfg.T, bool(training))
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = lib().sed_net_workspace_bytes(C.byref(cfg), int(training))
+            if nbytes == 0:
+                check(-1, "sed_net_workspace_bytes")
+            ws = torch.empty(nbytes // 4 + 64, device=self._arena.device, dtype=torch.float32)
+            if len(self._ws) >= 4:
+                self._ws.clear()
+            self._ws[key] = ws
+        return ws
+
+    def _check_input(self, x):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            raise _lib.SedHipError("sed_crnn_amd runs on an MI355X only: input must be a CUDA(HIP) tensor "
+                                   "(there is no CPU fallback; the CPU reference lives in oracle/ for tests)")
+        if self._arena is None or not self._arena.is_cuda:
+            raise _lib.SedHipError("sed_crnn_amd: move the module to the GPU first (model.to('cuda'))")
+        if x.dim() != 4 or x.shape[1] != self.in_channels or x.shape[2] != self.n_mels:
+            raise ValueError(f"expected input [B,{self.in_channels},{self.n_mels},T], got {tuple(x.shape)}")
+        if x.shape[3] % self.time_factor:
+            raise ValueError(f"T={x.shape[3]} must be a multiple of {self.time_factor}")
+
+    def _next_seed(self):
+        self._seed_counter += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_counter * 0xD1B54A32D192ED03) & _MASK64
+
+    # ── raw plan calls (also used by the fused trainer) ──
+    def _run_forward(self, x, training):
+        self._check_input(x)
+        x = x.contiguous().float()
+        B, _, _, T = x.shape
+        cfg = self._cfg(B, T)
+        P, _ = self._param_structs()
+        ws = self._workspace(cfg, training)
+        logits = torch.empty(B, T // self.time_factor, self.dense[-1], device=x.device, dtype=torch.float32)
+        if training:
+            self._ticket += 1
+            self._seed = self._next_seed()
+            self._nbt_pending += 1
+            self._last = (cfg, ws)
+        seed = self._seed if training else 0
+        check(lib().sed_net_forward(C.byref(cfg), C.byref(P), _lib.ptr(x), _lib.ptr(logits), _lib.ptr(ws),
+                                    int(training), seed, _lib.stream_ptr()), "sed_net_forward")
+        return logits
+
+    def _run_backward(self, x, dlogits, stage_begin=0, stage_end=None):
+        cfg, ws = self._last
+        P, G = self._param_structs()
+        if stage_end is None:
+            stage_end = len(self.conv_channels) + 1
+        check(lib().sed_net_backward(C.byref(cfg), C.byref(P), C.byref(G), _lib.ptr(x), _lib.ptr(dlogits),
+                                     _lib.ptr(ws), self._seed, stage_begin, stage_end, _lib.stream_ptr()),
+              "sed_net_backward")
+
+    # ── nn.Module surface ──
+    def forward(self, x):                                   # x [B,Cin,F,T] -> logits [B,T',K]
+        if self.training and torch.is_grad_enabled():
+            return _NetFn.apply(self, x, *self._arena_params)
+        return self._run_forward(x, training=self.training)
+
+    def _flush_nbt(self):
+        if self._nbt_pending:
+            for m in self.modules():
+                if isinstance(m, BNParams):
+                    m.num_batches_tracked += self._nbt_pending
+            self._nbt_pending = 0
+
+    def state_dict(self, *a, **k):
+        self._flush_nbt()
+        return super().state_dict(*a, **k)
+
+    def load_state_dict(self, sd, *a, **k):
+        self._nbt_pending = 0
+        out = super().load_state_dict(sd, *a, **k)     # copies in place: arena views stay valid
+        return out
+
+
+# ───────────────────────── the two reference networks ─────────────────────────
+class TimePooledCRNN(HipCRNN):
+    """Drop-in for reference sed.py:82-112: ``convs``/``bns`` ModuleLists, ``gru`` (2-layer BiGRU), ``fc``.
+
+    ``TimePooledCRNN(conv_channels=128, dropout=0.5)`` is the reference signature; the keyword-only
+    arguments open up what the reference hard-codes (sed.py:86,95,101) for the BASELINE configs.
+    """
+
+    def __init__(self, conv_channels=128, dropout=0.5, *, in_channels=1, n_mels=40, time_pool=(2, 2, 2),
+                 gru_hidden=32, gru_layers=2, n_classes=1):
+        super().__init__()
+        n = len(time_pool)
+        self._init_spec(in_channels=in_channels, n_mels=n_mels, conv_channels=[conv_channels] * n,
+                        pools=[(1, p) for p in time_pool], drops=[dropout] * n,     # dropout after EVERY block
+                        gru_hidden=[gru_hidden] * gru_layers, dense=[n_classes])
+        self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+        ch = in_channels
+        for _ in time_pool:
+            self.convs.append(ConvParams(ch, conv_channels))
+            self.bns.append(BNParams(conv_channels))
+            ch = conv_channels
+        self.flat = self.flat_features
+        self.gru = GRUParams(self.flat, gru_hidden, gru_layers)
+        self.fc = LinearParams(2 * gru_hidden, n_classes)
+        self._flatten()
+
+    def _roles(self):
+        L = len(self.gru_hidden)
+        gl = [[self.gru.layer(k, d) for d in range(2)] for k in range(L)]
+        return {
+            "conv_w": [c.weight for c in self.convs], "conv_b": [c.bias for c in self.convs],
+            "bn_g": [b.weight for b in self.bns], "bn_b": [b.bias for b in self.bns],
+            "bn_rm": [b.running_mean for b in self.bns], "bn_rv": [b.running_var for b in self.bns],
+            "gru_wih": [[gl[k][d][0] for d in range(2)] for k in range(L)],
+            "gru_whh": [[gl[k][d][1] for d in range(2)] for k in range(L)],
+            "gru_bih": [[gl[k][d][2] for d in range(2)] for k in range(L)],
+            "gru_bhh": [[gl[k][d][3] for d in range(2)] for k in range(L)],
+            "dense_w": [self.fc.weight], "dense_b": [self.fc.bias],
+        }
+
+
+class LightningTimePooledCRNN(HipCRNN):
+    """Drop-in for reference crnn_lightning.py:41-73: ``conv_stack`` (conv at 0,4,8; BN at 1,5,9; dropout
+    once at the end), ``gru1``, ``gru2``, ``d1`` (+ReLU), ``d2``; attributes ``T_out`` and ``_flat``."""
+
+    def __init__(self, dropout=0.4, *, in_channels=1, n_mels=40, conv_depth=16, time_pool=(2, 2, 2),
+                 gru1_units=16, gru2_units=8, dense1_units=8, n_classes=1, seq_len_in=64):
+        super().__init__()
+        n = len(time_pool)
+        self._init_spec(in_channels=in_channels, n_mels=n_mels, conv_channels=[conv_depth] * n,
+                        pools=[(1, p) for p in time_pool], drops=[0.0] * (n - 1) + [dropout],
+                        gru_hidden=[gru1_units, gru2_units], dense=[dense1_units, n_classes])
+        self.conv_stack = nn.Sequential()
+        ch = in_channels
+        for p in time_pool:
+            self.conv_stack.append(ConvParams(ch, conv_depth))
+            self.conv_stack.append(BNParams(conv_depth))
+            self.conv_stack.append(nn.Identity())           # ReLU slot (fused into the HIP kernel)
+            self.conv_stack.append(nn.Identity())           # MaxPool2d((1,p)) slot (fused)
+            ch = conv_depth
+        self.conv_stack.append(nn.Identity())               # Dropout slot (fused)
+        self.T_out = seq_len_in // self.time_factor
+        self._flat = self.flat_features
+        self.gru1 = GRUParams(self._flat, gru1_units)
+        self.gru2 = GRUParams(2 * gru1_units, gru2_units)
+        self.d1 = LinearParams(2 * gru2_units, dense1_units)
+        self.d2 = LinearParams(dense1_units, n_classes)
+        self._flatten()
+
+    def _roles(self):
+        n = len(self.conv_channels)
+        convs = [self.conv_stack[4 * i] for i in range(n)]
+        bns = [self.conv_stack[4 * i + 1] for i in range(n)]
+        g = [[self.gru1.layer(0, d) for d in range(2)], [self.gru2.layer(0, d) for d in range(2)]]
+        return {
+            "conv_w": [c.weight for c in convs], "conv_b": [c.bias for c in convs],
+            "bn_g": [b.weight for b in bns], "bn_b": [b.bias for b in bns],
+            "bn_rm": [b.running_mean for b in bns], "bn_rv": [b.running_var for b in bns],
+            "gru_wih": [[g[k][d][0] for d in range(2)] for k in range(2)],
+            "gru_whh": [[g[k][d][1] for d in range(2)] for k in range(2)],
+            "gru_bih": [[g[k][d][2] for d in range(2)] for k in range(2)],
+            "gru_bhh": [[g[k][d][3] for d in range(2)] for k in range(2)],
+            "dense_w": [self.d1.weight, self.d2.weight], "dense_b": [self.d1.bias, self.d2.bias],
+        }
+
+
+class SEDNet(HipCRNN):
+    """General topology behind ``get_model``: per-block (pool_f, pool_t), stacked BiGRUs, dense head.
+    State-dict keys: convs.{l}, bns.{l}, grus.{i}, fcs.{j}."""
+
+    def __init__(self, in_channels, n_mels, conv_channels, pools, rnn_hidden, fc, dropout, dropout_every_block=True):
+        super().__init__()
+        n = len(pools)
+        chans = [conv_channels] * n if isinstance(conv_channels, int) else list(conv_channels)
+        drops = [dropout] * n if dropout_every_block else [0.0] * (n - 1) + [dropout]
+        self._init_spec(in_channels=in_channels, n_mels=n_mels, conv_channels=chans, pools=pools, drops=drops,
+                        gru_hidden=list(rnn_hidden), dense=list(fc))
+        self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+        ch = in_channels
+        for c in chans:
+            self.convs.append(ConvParams(ch, c))
+            self.bns.append(BNParams(c))
+            ch = c
+        self.grus, self.fcs = nn.ModuleList(), nn.ModuleList()
+        fin = self.flat_features
+        for h in rnn_hidden:
+            self.grus.append(GRUParams(fin, h))
+            fin = 2 * h
+        for d in fc:
+            self.fcs.append(LinearParams(fin, d))
+            fin = d
+        self._flatten()
+
+    def _roles(self):
+        g = [[m.layer(0, d) for d in range(2)] for m in self.grus]
+        n = len(g)
+        return {
+            "conv_w": [c.weight for c in self.convs], "conv_b": [c.bias for c in self.convs],
+            "bn_g": [b.weight for b in self.bns], "bn_b": [b.bias for b in self.bns],
+            "bn_rm": [b.running_mean for b in self.bns], "bn_rv": [b.running_var for b in self.bns],
+            "gru_wih": [[g[k][d][0] for d in range(2)] for k in range(n)],
+            "gru_whh": [[g[k][d][1] for d in range(2)] for k in range(n)],
+            "gru_bih": [[g[k][d][2] for d in range(2)] for k in range(n)],
+            "gru_bhh": [[g[k][d][3] for d in range(2)] for k in range(n)],
+            "dense_w": [m.weight for m in self.fcs], "dense_b": [m.bias for m in self.fcs],
+        }
+
+
+def get_model(in_channels=1, n_mels=40, seq_len=256, n_classes=1, conv_channels=128,
+              pools=((1, 2), (1, 2), (1, 2)), rnn_hidden=(32, 32), fc=None, dropout=0.5,
+              dropout_every_block=True):
+    """Factory named by the reference README (README.md:44; its body is not in the reference tree).
+
+    ``pools`` are (pool_mel, pool_time) per conv block: the fork's time-pooled net is the default; the
+    README figure's original SEDnet is ``pools=[(5,1),(2,1),(2,1)], n_classes=6, fc=[16, 6]``.
+    ``fc`` lists the dense sizes after the GRUs (ReLU between them); default ``[n_classes]``.
+    ``seq_len`` is validated against the time pooling and otherwise free (the kernels take any T).
+    """
+    tf = math.prod(p[1] for p in pools)
+    if seq_len % tf:
+        raise ValueError(f"seq_len={seq_len} is not divisible by the total time pooling {tf}")
+    fc = [n_classes] if fc is None else list(fc)
+    if fc[-1] != n_classes:
+        raise ValueError("the last dense size must equal n_classes")
+    return SEDNet(in_channels, n_mels, conv_channels, [tuple(p) for p in pools], list(rnn_hidden), fc, dropout,
+                  dropout_every_block)

@@ -1,0 +1,191 @@
+"""Per-kernel Python entry points over the C ABI (torch tensors in, torch tensors out).
+
+These are thin: they allocate outputs/workspaces with torch (device memory plumbing) and call
+libsedcrnn.so on torch's current stream.  Used by the parity tests and by feature extraction; the
+network itself goes through the whole-network plan (`model.py` -> sed_net_forward/backward).
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def _f32c(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expect contiguous fp32 CUDA tensor"
+    return t
+
+
+def conv3x3_pack(w):
+    Cout, Cin = w.shape[:2]
+    wf = torch.empty(9, Cout, Cin, device=w.device)
+    wd = torch.empty(9, Cin, Cout, device=w.device)
+    check(lib().sed_conv3x3_pack_weights(ptr(_f32c(w)), ptr(wf), ptr(wd), Cout, Cin, stream_ptr()), "conv3x3_pack")
+    return wf, wd
+
+
+def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True):
+    """x: [B,Cin,F,T] if x_is_nchw else [B,T,F,Cin]; wp [9,Cout,Cin] -> y [B,T,F,Cout] (+ stat partials)."""
+    if x_is_nchw:
+        B, Cin, F, T = x.shape
+    else:
+        B, T, F, Cin = x.shape
+    Cout = wp.shape[1]
+    y = torch.empty(B, T, F, Cout, device=x.device)
+    stat = None
+    if want_stats:
+        rows = lib().sed_conv3x3_stat_rows(B, Cin, F, T, Cout, int(x_is_nchw))
+        stat = torch.zeros(max(rows, 1), 2, Cout, device=x.device)
+    check(lib().sed_conv3x3_fwd(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(wp)), ptr(bias), ptr(y), ptr(stat),
+                                B, Cin, F, T, Cout, stream_ptr()), "conv3x3_fwd")
+    return y, stat
+
+
+def conv3x3_wgrad(x, dy, x_is_nchw):
+    if x_is_nchw:
+        B, Cin, F, T = x.shape
+    else:
+        B, T, F, Cin = x.shape
+    Cout = dy.shape[-1]
+    nbytes = lib().sed_conv3x3_wgrad_workspace_bytes(B, Cin, F, T, Cout)
+    ws = torch.empty(nbytes // 4 + 1, device=x.device)
+    dw = torch.empty(Cout, Cin, 3, 3, device=x.device)
+    check(lib().sed_conv3x3_wgrad(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(dy)), ptr(dw), ptr(ws),
+                                  B, Cin, F, T, Cout, stream_ptr()), "conv3x3_wgrad")
+    return dw
+
+
+def bn_finalize_train(stat, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    rows, _, Cc = stat.shape
+    mean, rstd, scale, shift = (torch.empty(Cc, device=stat.device) for _ in range(4))
+    check(lib().sed_bn_finalize_train(ptr(stat), rows, Cc, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                                      ptr(running_var), momentum, eps, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+                                      stream_ptr()), "bn_finalize_train")
+    return mean, rstd, scale, shift
+
+
+def bn_finalize_eval(gamma, beta, rm, rv, eps=1e-5):
+    Cc = gamma.numel()
+    scale, shift = torch.empty(Cc, device=gamma.device), torch.empty(Cc, device=gamma.device)
+    check(lib().sed_bn_finalize_eval(ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, Cc, ptr(scale), ptr(shift),
+                                     stream_ptr()), "bn_finalize_eval")
+    return scale, shift
+
+
+def bn_relu_pool_drop_fwd(y, scale, shift, pool_f, pool_t, out_tcf=False, drop_p=0.0, seed=0):
+    B, T, F, Cc = y.shape
+    Tp, Fp = T // pool_t, F // pool_f
+    out = torch.empty((B, Tp, Cc, Fp) if out_tcf else (B, Tp, Fp, Cc), device=y.device)
+    check(lib().sed_bn_relu_pool_drop_fwd(ptr(_f32c(y)), ptr(scale), ptr(shift), ptr(out), B, T, F, Cc, pool_f, pool_t,
+                                          int(out_tcf), drop_p, seed, stream_ptr()), "bn_relu_pool_drop_fwd")
+    return out
+
+
+def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out_tcf=False, drop_p=0.0, seed=0):
+    """-> (dy [B,T,F,C], dgamma, dbeta, dbias)"""
+    B, T, F, Cc = y.shape
+    rows = lib().sed_bn_bwd_rows(B, T, pool_t)
+    part = torch.empty(rows, 2, Cc, device=y.device)
+    check(lib().sed_bn_relu_pool_drop_bwd_reduce(ptr(_f32c(y)), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean),
+                                                 ptr(rstd), ptr(part), B, T, F, Cc, pool_f, pool_t, int(out_tcf),
+                                                 drop_p, seed, stream_ptr()), "bn_bwd_reduce")
+    sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=y.device) for _ in range(4))
+    check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta),
+                                    stream_ptr()), "bn_bwd_finalize")
+    dy = torch.empty_like(y)
+    dbp = torch.empty(rows, Cc, device=y.device)
+    check(lib().sed_bn_relu_pool_drop_bwd_apply(ptr(y), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                                                ptr(sum_g), ptr(sum_gx), ptr(dy), ptr(dbp), B, T, F, Cc, pool_f,
+                                                pool_t, int(out_tcf), drop_p, seed, stream_ptr()), "bn_bwd_apply")
+    dbias = torch.empty(Cc, device=y.device)
+    check(lib().sed_reduce_rows(ptr(dbp), rows, Cc, Cc, ptr(dbias), stream_ptr()), "reduce_rows")
+    return dy, dgamma, dbeta, dbias
+
+
+def gemm(A, B, bias=None, out=None, beta=0.0):
+    """out = A @ B (+bias) (+beta*out) for 2-D fp32 CUDA tensors with arbitrary (unit-along-one-axis) strides."""
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty(M, N, device=A.device)
+    check(lib().sed_gemm_f32(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
+                             out.stride(0), ptr(bias), beta, M, N, K, stream_ptr()), "gemm_f32")
+    return out
+
+
+def linear_fwd(x, W, b, relu=False):
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, device=x.device)
+    check(lib().sed_linear_fwd(ptr(_f32c(x)), ptr(_f32c(W)), ptr(b), ptr(y), M, K, N, int(relu), stream_ptr()), "linear_fwd")
+    return y
+
+
+def linear_bwd(x, W, y, dy, relu=False, need_dx=True):
+    M, K = x.shape
+    N = W.shape[0]
+    ws = torch.empty(lib().sed_linear_bwd_workspace_bytes(M, K, N) // 4 + 1, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    dW, db = torch.empty_like(W), torch.empty(N, device=x.device)
+    dy = dy.clone()
+    check(lib().sed_linear_bwd(ptr(x), ptr(W), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db), ptr(ws), M, K, N,
+                               int(relu), stream_ptr()), "linear_bwd")
+    return dx, dW, db
+
+
+def _pp(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def gru_seq_fwd(gi, whh, bhh, save=True):
+    """gi [B,T,2,3H]; whh/bhh: pairs (forward, reverse) -> out [B,T,2H], saved [B,T,2,5,H]"""
+    B, T, _, H3 = gi.shape
+    H = H3 // 3
+    out = torch.empty(B, T, 2 * H, device=gi.device)
+    saved = torch.empty(B, T, 2, 5, H, device=gi.device) if save else None
+    ws = torch.empty(lib().sed_gru_seq_workspace_bytes(H) // 4, device=gi.device)
+    check(lib().sed_gru_seq_fwd(ptr(_f32c(gi)), _pp(whh), _pp(bhh), ptr(out), ptr(saved), ptr(ws), B, T, H,
+                                stream_ptr()), "gru_seq_fwd")
+    return out, saved
+
+
+def gru_seq_bwd(dout, saved, whh):
+    B, T, H2 = dout.shape
+    H = H2 // 2
+    dgi = torch.empty(B, T, 2, 3 * H, device=dout.device)
+    dgh = torch.empty(B, T, 2, 3 * H, device=dout.device)
+    check(lib().sed_gru_seq_bwd(ptr(_f32c(dout)), ptr(saved), _pp(whh), ptr(dgi), ptr(dgh), B, T, H, stream_ptr()),
+          "gru_seq_bwd")
+    return dgi, dgh
+
+
+def loss_fwd_bwd(logits, targets, kind="bce", alpha=0.25, gamma=2.0, reduction="mean"):
+    """-> (loss scalar tensor, dlogits, probs)"""
+    n = logits.numel()
+    loss = torch.empty(1, device=logits.device)
+    d = torch.empty_like(logits)
+    p = torch.empty_like(logits)
+    check(lib().sed_loss_fwd_bwd(ptr(_f32c(logits)), ptr(_f32c(targets)), n, 0 if kind == "bce" else 1, alpha, gamma,
+                                 int(reduction == "mean"), ptr(loss), ptr(d), ptr(p), stream_ptr()), "loss_fwd_bwd")
+    return loss, d, p
+
+
+def sigmoid(x):
+    y = torch.empty_like(x)
+    check(lib().sed_sigmoid(ptr(_f32c(x)), ptr(y), x.numel(), stream_ptr()), "sigmoid")
+    return y
+
+
+def grad_norm_clip_coef(g, max_norm):
+    """-> tensor [norm, coef] on device (no host sync)"""
+    out = torch.empty(2, device=g.device)
+    ws = torch.empty(lib().sed_sqnorm_workspace_bytes(g.numel()) // 4, device=g.device)
+    check(lib().sed_grad_norm_clip_coef(ptr(g), g.numel(), float(max_norm), ptr(out), ptr(ws), stream_ptr()), "grad_norm")
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+    check(lib().sed_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                              ptr(grad_scale), stream_ptr()), "adam_step")

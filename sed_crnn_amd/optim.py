@@ -1,0 +1,78 @@
+"""Fused Adam on the flat parameter arena (one HIP launch), plus global-norm gradient clipping.
+
+Semantics of torch.optim.Adam as configured by the reference (sed.py:159 ``Adam(lr=1e-3)``;
+crnn_lightning.py:195-197 ``Adam(lr, weight_decay=1e-4)`` = coupled L2, not AdamW) and of
+``gradient_clip_val=1.0`` (train_lightning.py:50: global L2 norm, coefficient min(1, c/(norm+1e-6))).
+The clip coefficient stays on the device (no host sync).
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """``FusedAdam(model.parameters(), lr=1e-3, weight_decay=0)`` — drop-in for torch.optim.Adam.
+
+    When the parameters are the views of one HipCRNN arena and their grads are the arena's grad views the
+    whole update is a single launch; otherwise one launch per parameter.  ``max_grad_norm`` fuses
+    clip_grad_norm_ into the step.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+        self._arena = None          # (flat_p, flat_g, m, v) once detected
+
+    def attach(self, model):
+        """Use the model's flat arenas explicitly (fused trainer path)."""
+        p, g = model.flat_parameters(), model.flat_grads()
+        self._arena = (p, g, torch.zeros_like(p), torch.zeros_like(p))
+        self._arena_model = model
+        return self
+
+    def _arena_ok(self):
+        if self._arena is None:
+            return False
+        m = self._arena_model
+        if m.flat_parameters() is not self._arena[0]:
+            return False                                     # the model was moved: arenas were rebuilt
+        return all(p.grad is not None and p.grad.data_ptr() == g.data_ptr()
+                   for p, g in zip(m._arena_params, m._grad_views))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
+            mgn = group["max_grad_norm"]
+            group.setdefault("step", 0)
+            group["step"] += 1
+            t = group["step"]
+            if self._arena_ok() and len(self.param_groups) == 1:
+                p, g, m, v = self._arena
+                coef = ops.grad_norm_clip_coef(g, mgn)[1:2] if mgn else None
+                ops.adam_step(p, g, m, v, lr, b1, b2, eps, wd, t, coef)
+                continue
+            ps = [p for p in group["params"] if p.grad is not None]
+            coef = None
+            if mgn:
+                flat = torch.cat([p.grad.reshape(-1) for p in ps])
+                pad = (-flat.numel()) % 4
+                if pad:
+                    flat = torch.cat([flat, flat.new_zeros(pad)])
+                coef = ops.grad_norm_clip_coef(flat, mgn)[1:2]
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+                gr = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                ops.adam_step(p.data, gr, st["m"], st["v"], lr, b1, b2, eps, wd, t, coef)
+        return loss
+
+
+def clip_grad_norm_(model, max_norm):
+    """Global-norm clip over the model's flat gradient arena; returns the device tensor [norm, coef]."""
+    g = model.flat_grads()
+    out = ops.grad_norm_clip_coef(g, max_norm)
+    g.mul_(out[1])
+    return out

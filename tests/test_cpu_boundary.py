@@ -1,0 +1,145 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/sedcrnn.h declares, the host
+mirror keeps the reference's state_dict contract, the product metrics match the oracle and the goldens."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sedcrnn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sed_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from sed_crnn_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in sedcrnn.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header drifted apart"
+    assert _lib.lib().sed_version() >= 100
+    assert _lib.lib().sed_last_error_string() is not None
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from sed_crnn_amd import _lib
+    L = _lib.lib()
+    rc = L.sed_conv3x3_fwd(None, 0, None, None, None, None, 1, 1, 40, 8, 8, None)
+    assert rc < 0 and b"null pointer" in L.sed_last_error_string()
+    rc = L.sed_gemm_f32(1, 3, 2, 1, 1, 1, 1, 4, None, 0.0, 4, 4, 4, None)        # neither A stride is 1
+    assert rc < 0 and b"contiguous" in L.sed_last_error_string()
+    cfg = _lib.NetCfg()
+    assert L.sed_net_workspace_bytes(cfg, 1) == 0                                  # empty config is rejected
+    with pytest.raises(_lib.SedHipError):
+        _lib.check(rc, "gemm")
+
+
+def test_net_workspace_and_shapes_for_baseline_configs():
+    import ctypes as C
+    import sed_crnn_amd as sed
+    from sed_crnn_amd import _lib
+    m = sed.TimePooledCRNN(conv_channels=128, dropout=0.5, gru_hidden=128)
+    cfg = m._cfg(128, 256)
+    tp, fp = C.c_int(), C.c_int()
+    assert _lib.lib().sed_net_out_shape(C.byref(cfg), C.byref(tp), C.byref(fp)) == 0
+    assert (tp.value, fp.value) == (32, 40)
+    tr, ev = (_lib.lib().sed_net_workspace_bytes(C.byref(cfg), t) for t in (1, 0))
+    assert 2e9 < tr < 6e9 and ev < tr                   # ~3 GB of activations at B=128: trivial vs 288 GB HBM
+    m5 = sed.TimePooledCRNN(conv_channels=128, dropout=0.5, in_channels=4, n_mels=128, gru_hidden=256)
+    assert _lib.lib().sed_net_workspace_bytes(C.byref(m5._cfg(128, 512)), 1) > 0      # config 5 is plannable
+    bad = m._cfg(128, 256)
+    bad.pool_t[0] = 3
+    assert _lib.lib().sed_net_workspace_bytes(C.byref(bad), 1) == 0
+
+
+def test_state_dict_contract_matches_reference_goldens():
+    import sed_crnn_amd as sed
+    d = load_golden("g1_sed_c8.npz")
+    m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0)
+    ref_keys = [k[3:] for k in d if k.startswith("sd.")]
+    assert list(m.state_dict().keys()) == ref_keys
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == d["sd." + k].shape, k
+    m.load_state_dict({k: torch.from_numpy(np.asarray(d["sd." + k])) for k in ref_keys})
+    assert np.array_equal(m.state_dict()["gru.weight_ih_l1_reverse"].numpy(), d["sd.gru.weight_ih_l1_reverse"])
+    # parameters are views of one flat arena in backward-completion order
+    flat = m.flat_parameters()
+    assert all(p.data_ptr() >= flat.data_ptr() and p.data_ptr() < flat.data_ptr() + flat.numel() * 4 for p in m.parameters())
+    sl = m.bucket_slices()
+    assert sl[0][0] == 0 and sl[-1][1] == flat.numel() and len(sl) == 4
+    d4 = load_golden("g4_lightning.npz")
+    l = sed.LightningTimePooledCRNN(dropout=0.0)
+    assert list(l.state_dict().keys()) == [k[3:] for k in d4 if k.startswith("sd.")]
+    assert l.T_out == 8 and l._flat == 640
+    assert sum(p.numel() for p in l.parameters()) == 70225            # Lightning net parameter count
+    assert sum(p.numel() for p in sed.TimePooledCRNN().parameters()) == 1305665
+
+
+def test_default_init_equals_torch_nn_under_the_same_seed():
+    import sed_crnn_amd as sed
+    from oracle import crnn_ref
+    torch.manual_seed(123)
+    a = sed.TimePooledCRNN(conv_channels=16, dropout=0.1)
+    torch.manual_seed(123)
+    b = crnn_ref.SedNetRef(conv_channels=16, dropout=0.1)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+
+
+def test_product_metrics_match_oracle_and_goldens():
+    import sed_crnn_amd as sed
+    from oracle import metrics_ref
+    d = load_golden("g6_metrics.npz")
+    sc = sed.metrics.compute_scores(d["p"] > 0.5, d["t"], 5)
+    assert sc["f1_overall_1sec"] == float(d["f1_1s"]) and sc["er_overall_1sec"] == float(d["er_1s"])
+    assert sed.metrics.f1_overall_framewise(d["p"] > 0.5, d["t"]) == float(d["f1_fr"])
+    assert sed.metrics.er_overall_framewise(d["p"] > 0.5, d["t"]) == float(d["er_fr"])
+    rng = np.random.default_rng(7)
+    for K in (1, 6):
+        for n in (1, 7, 48, 50):
+            p = rng.random((n, 3, K)) > 0.5
+            t = (rng.random((n, 3, K)) > 0.5).astype(np.float32)
+            for blk in (1, 4, 5, 7, 200):
+                a, b = sed.metrics.compute_scores(p, t, blk), metrics_ref.compute_scores(p, t, blk)
+                for k in a:
+                    assert a[k] == b[k] or (np.isnan(a[k]) and np.isnan(b[k])), (K, n, blk, k)
+    z, o = np.zeros((4, 8, 1), np.float32), np.ones((4, 8, 1), np.float32)
+    assert sed.metrics.f1_overall_1sec(o, z, 5) == 0.0 and np.isinf(sed.metrics.er_overall_1sec(o, z, 5))
+    assert np.isnan(sed.metrics.er_overall_1sec(z, z, 5))
+
+
+def test_g7_dataset_helper_semantics_are_documented_by_golden():
+    d = load_golden("g7_dataset.npz")
+    lab = d["lab"]
+    # clean negatives = window starts whose 64-frame window holds no positive frame (sed.py:48-52)
+    mask = (lab[:, 0] == 1).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(mask)])
+    starts = np.where(cs[64:] - cs[:-64] == 0)[0]
+    assert np.array_equal(starts, d["neg_starts"])
+    assert np.array_equal(lab[60:124].reshape(8, -1).max(axis=1, keepdims=True), d["pooled_60"])
+    assert int(d["len"]) == 2 * len(d["pos_frames"])
+
+
+def test_mel_basis_and_logmel_oracle_properties():
+    from oracle import logmel_ref
+    from sed_crnn_amd.feature import slaney_mel_basis
+    fb = logmel_ref.mel_filterbank()
+    assert fb.shape == (40, 1025) and fb.dtype == np.float32 and (fb >= 0).all()
+    np.testing.assert_array_equal(slaney_mel_basis(), fb)
+    # Slaney area normalisation: every triangle integrates to ~1 over Hz (bin spacing sr/n_fft)
+    area = fb.sum(1) * (44100 / 2048)
+    assert np.all(np.abs(area[5:] - 1.0) < 0.05)
+    y = np.sin(2 * np.pi * 1000 * np.arange(8192) / 44100).astype(np.float32)
+    m = logmel_ref.mbe(y)
+    assert m.shape == (1 + 8192 // 1024, 40)
+    peak_hz = 0.5 * (np.argmax(fb[m[4].argmax()]) * 44100 / 2048 + 1000)
+    assert abs(peak_hz - 1000) < 120                                   # energy lands in the band around 1 kHz
+    assert np.isneginf(logmel_ref.mbe(np.zeros(4096, np.float32))).all()   # log without epsilon (feature.py:59)

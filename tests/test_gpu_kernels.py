@@ -1,0 +1,289 @@
+"""Per-kernel parity: every HIP kernel of libsedcrnn.so (called through the C ABI) against a plain
+torch fp32 CPU reference of the same op.  Tolerances are stated per test; fp32 everywhere."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sed_crnn_amd import ops as o
+    return o
+
+
+def g(t):
+    return t.cuda().contiguous()
+
+
+def close(a, b, atol, rtol=1e-4, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=atol, rtol=rtol, err_msg=msg)
+
+
+CONV_CASES = [  # B, Cin, F, T, Cout, nchw
+    (2, 1, 40, 16, 8, True), (3, 1, 40, 18, 128, True), (2, 2, 40, 8, 128, True), (2, 4, 128, 8, 128, True),
+    (2, 8, 40, 8, 8, False), (2, 16, 40, 10, 16, False),
+    (2, 128, 40, 12, 128, False), (1, 128, 40, 7, 128, False), (2, 32, 40, 8, 32, False), (2, 64, 20, 8, 64, False),
+    (1, 128, 128, 4, 128, False), (2, 128, 40, 8, 256, False),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Fm,T,Cout,nchw", CONV_CASES)
+def test_conv3x3_fwd_stats_dgrad_wgrad(ops, B, Cin, Fm, T, Cout, nchw):
+    gen = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    x = torch.randn(B, Cin, Fm, T, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / np.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, padding=1)                       # [B,Cout,F,T]
+    dy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(dy)
+    wf, wd = ops.conv3x3_pack(g(w))
+    xin = g(x) if nchw else g(x.permute(0, 3, 2, 1))             # channels-last [B,T,F,Cin]
+    y, stat = ops.conv3x3_fwd(xin, wf, g(b), nchw)
+    y_ref_cl = y_ref.detach().permute(0, 3, 2, 1)                # [B,T,F,Cout]
+    close(y, y_ref_cl, atol=2e-5, rtol=1e-4)
+    s = stat.sum(0).cpu()
+    np.testing.assert_allclose(s[0].numpy(), y_ref_cl.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(s[1].numpy(), (y_ref_cl ** 2).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=2e-3)
+    # weight gradient
+    dy_cl = g(dy.permute(0, 3, 2, 1))
+    dw = ops.conv3x3_wgrad(xin, dy_cl, nchw)
+    close(dw, wr.grad, atol=2e-4, rtol=2e-4)
+    # data gradient = forward kernel on dy with the flipped/transposed pack
+    if Cin % 4 == 0:
+        dx, _ = ops.conv3x3_fwd(dy_cl, wd, None, False, want_stats=False)
+        close(dx, xr.grad.permute(0, 3, 2, 1), atol=2e-5, rtol=1e-4)
+
+
+POOL_CASES = [  # B,T,F,C,pf,pt,tcf
+    (2, 8, 40, 8, 1, 2, False), (2, 8, 40, 128, 1, 2, False), (2, 8, 40, 128, 1, 2, True), (3, 4, 40, 16, 1, 2, True),
+    (2, 4, 40, 32, 5, 1, False), (2, 4, 8, 32, 2, 1, True), (2, 8, 8, 16, 2, 2, False), (2, 6, 40, 8, 1, 1, True),
+]
+
+
+def _bn_block_ref(y_nchw, gamma, beta, pf, pt, eps=1e-5):
+    z = F.batch_norm(y_nchw, None, None, gamma, beta, training=True, eps=eps)
+    return F.max_pool2d(torch.relu(z), (pf, pt))
+
+
+@pytest.mark.parametrize("B,T,Fm,Cc,pf,pt,tcf", POOL_CASES)
+def test_bn_relu_pool_fwd_bwd(ops, B, T, Fm, Cc, pf, pt, tcf):
+    gen = torch.Generator().manual_seed(T * 100 + Cc + pf)
+    y = torch.randn(B, Cc, Fm, T, generator=gen) * 1.5 + 0.3          # NCHW reference layout
+    gamma = torch.rand(Cc, generator=gen) + 0.5
+    beta = torch.randn(Cc, generator=gen) * 0.2
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out_ref = _bn_block_ref(yr, gr, br, pf, pt)                       # [B,C,F',T']
+    dout = torch.randn(out_ref.shape, generator=gen)
+    out_ref.backward(dout)
+    y_cl = g(y.permute(0, 3, 2, 1))                                   # [B,T,F,C]
+    # statistics from partial sums, as the conv epilogue produces them
+    part = torch.stack([y_cl.reshape(-1, Cc).sum(0), (y_cl.reshape(-1, Cc) ** 2).sum(0)]).reshape(1, 2, Cc).contiguous()
+    rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
+    mean, rstd, scale, shift = ops.bn_finalize_train(part, B * T * Fm, g(gamma), g(beta), rm, rv)
+    close(mean, y.mean((0, 2, 3)), atol=1e-5)
+    close(rstd, 1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5), atol=1e-5, rtol=1e-4)
+    close(rm, 0.1 * y.mean((0, 2, 3)), atol=1e-6)
+    close(rv, 0.9 + 0.1 * y.var((0, 2, 3), unbiased=True), atol=1e-5)
+    out = ops.bn_relu_pool_drop_fwd(y_cl, scale, shift, pf, pt, out_tcf=tcf)
+    ref = out_ref.detach().permute(0, 3, 1, 2) if tcf else out_ref.detach().permute(0, 3, 2, 1)
+    close(out, ref, atol=1e-5, rtol=1e-4)
+    d_in = dout.permute(0, 3, 1, 2) if tcf else dout.permute(0, 3, 2, 1)
+    dy, dgamma, dbeta, dbias = ops.bn_relu_pool_drop_bwd(y_cl, g(d_in), scale, shift, mean, rstd, pf, pt, out_tcf=tcf)
+    close(dy, yr.grad.permute(0, 3, 2, 1), atol=2e-5, rtol=1e-3)
+    close(dgamma, gr.grad, atol=1e-4, rtol=1e-3)
+    close(dbeta, br.grad, atol=1e-4, rtol=1e-3)
+    assert float(dbias.abs().max()) < 1e-3                            # sum of BN input grads is 0 up to rounding
+
+
+def test_bn_eval_scale_shift(ops):
+    Cc = 16
+    gen = torch.Generator().manual_seed(5)
+    gamma, beta, rm = (torch.randn(Cc, generator=gen) for _ in range(3))
+    rv = torch.rand(Cc, generator=gen) + 0.5
+    scale, shift = ops.bn_finalize_eval(g(gamma), g(beta), g(rm), g(rv))
+    y = torch.randn(2, Cc, 8, 4, generator=gen)
+    ref = F.max_pool2d(torch.relu(F.batch_norm(y, rm, rv, gamma, beta, training=False)), (1, 2))
+    out = ops.bn_relu_pool_drop_fwd(g(y.permute(0, 3, 2, 1)), scale, shift, 1, 2)
+    close(out, ref.permute(0, 3, 2, 1), atol=1e-5)
+
+
+@pytest.mark.parametrize("tcf", [False, True])
+def test_dropout_mask_statistics_and_backward_consistency(ops, tcf):
+    B, T, Fm, Cc, p = 4, 16, 40, 128, 0.5
+    y = torch.rand(B, T, Fm, Cc).cuda() + 0.5                          # strictly positive: relu/pool transparent
+    scale, shift = torch.ones(Cc).cuda(), torch.zeros(Cc).cuda()
+    mean, rstd = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
+    out = ops.bn_relu_pool_drop_fwd(y, scale, shift, 1, 2, out_tcf=tcf, drop_p=p, seed=1234)
+    base = ops.bn_relu_pool_drop_fwd(y, scale, shift, 1, 2, out_tcf=tcf, drop_p=0.0)
+    kept = out != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    close(out[kept], (base * 2.0)[kept], atol=1e-6)                    # inverted-dropout scaling 1/(1-p)
+    out2 = ops.bn_relu_pool_drop_fwd(y, scale, shift, 1, 2, out_tcf=tcf, drop_p=p, seed=1234)
+    assert torch.equal(out, out2)                                      # same seed -> same mask
+    out3 = ops.bn_relu_pool_drop_fwd(y, scale, shift, 1, 2, out_tcf=tcf, drop_p=p, seed=1235)
+    assert not torch.equal(out, out3)
+    # backward regenerates the same mask: with sum_g/sum_gx forced to 0 the routed gradient is dout*mask*2
+    dout = torch.ones_like(out)
+    from sed_crnn_amd._lib import lib, ptr, stream_ptr, check
+    dy = torch.empty_like(y)
+    rows = lib().sed_bn_bwd_rows(B, T, 2)
+    dbp = torch.empty(rows, Cc).cuda()
+    z = torch.zeros(Cc).cuda()
+    check(lib().sed_bn_relu_pool_drop_bwd_apply(ptr(y), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(z), ptr(z),
+                                                ptr(dy), ptr(dbp), B, T, Fm, Cc, 1, 2, int(tcf), p, 1234, stream_ptr()))
+    routed = dy.reshape(B, T // 2, 2, Fm, Cc).sum(2)                   # one of each time pair carries the gradient
+    mask = kept.permute(0, 1, 3, 2) if tcf else kept
+    close(routed, mask.float() * 2.0, atol=1e-6)
+
+
+GEMM_CASES = [(64, 64, 64), (130, 70, 50), (4096, 96, 320), (256, 384, 5120), (384, 640, 512), (33, 17, 9), (512, 768, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_CASES)
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_f32_layouts(ops, M, N, K, ta, tb):
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=gen)
+    Bm = torch.randn(K, N, generator=gen)
+    bias = torch.randn(N, generator=gen)
+    Ag = g(A.t()).t() if ta else g(A)            # ta: stored [K][M] (contiguous along i)
+    Bg = g(Bm.t()).t() if tb else g(Bm)          # tb: stored [N][K] (contiguous along k)
+    ref = A.double() @ Bm.double() + bias.double()
+    out = ops.gemm(Ag, Bg, bias=g(bias))
+    tol = 2e-6 * K ** 0.5 * 10
+    close(out, ref.float(), atol=tol * 4, rtol=1e-4)
+    out2 = ops.gemm(Ag, Bg, out=out.clone(), beta=1.0)
+    close(out2, (ref + A.double() @ Bm.double()).float(), atol=tol * 8, rtol=1e-4)
+
+
+def test_gemm_strided_column_block(ops):
+    """the GRU projection writes into a column block of gi [M, 6H] (ldc > N) and reads strided operands"""
+    M, K, H = 96, 80, 8
+    gen = torch.Generator().manual_seed(1)
+    x, w, b = torch.randn(M, K, generator=gen), torch.randn(3 * H, K, generator=gen), torch.randn(3 * H, generator=gen)
+    gi = torch.zeros(M, 6 * H).cuda()
+    ops.gemm(g(x), g(w).t(), bias=g(b), out=gi[:, 3 * H:])
+    close(gi[:, 3 * H:], x @ w.t() + b, atol=1e-4)
+    assert float(gi[:, :3 * H].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(64, 64, 1, False), (100, 16, 8, True), (33, 256, 6, False), (7, 8, 1, True)])
+def test_linear_small_fwd_bwd(ops, M, K, N, relu):
+    gen = torch.Generator().manual_seed(M + K + N)
+    x, W, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) * 0.3, torch.randn(N, generator=gen)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    y_ref = F.linear(xr, Wr, br)
+    if relu:
+        y_ref = torch.relu(y_ref)
+    dy = torch.randn(M, N, generator=gen)
+    y_ref.backward(dy)
+    y = ops.linear_fwd(g(x), g(W), g(b), relu)
+    close(y, y_ref, atol=1e-5, rtol=1e-4)
+    dx, dW, db = ops.linear_bwd(g(x), g(W), y, g(dy), relu)
+    close(dx, xr.grad, atol=1e-5, rtol=1e-4)
+    close(dW, Wr.grad, atol=1e-4, rtol=1e-4)
+    close(db, br.grad, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 8, 32), (5, 8, 16), (3, 4, 8), (6, 16, 128), (4, 6, 20), (2, 5, 64), (3, 4, 136)])
+def test_gru_recurrence_fwd_bwd(ops, B, T, H):
+    In = 24
+    torch.manual_seed(H + B)
+    ref = torch.nn.GRU(In, H, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, In, requires_grad=True)
+    out_ref, _ = ref(x)
+    dout = torch.randn(B, T, 2 * H)
+    out_ref.backward(dout)
+    wih = [ref.weight_ih_l0, ref.weight_ih_l0_reverse]
+    whh = [ref.weight_hh_l0, ref.weight_hh_l0_reverse]
+    bih = [ref.bias_ih_l0, ref.bias_ih_l0_reverse]
+    bhh = [ref.bias_hh_l0, ref.bias_hh_l0_reverse]
+    gi = torch.stack([x.detach() @ wih[d].detach().t() + bih[d].detach() for d in range(2)], dim=2)   # [B,T,2,3H]
+    whh_g, bhh_g = [g(w.detach()) for w in whh], [g(b.detach()) for b in bhh]
+    out, saved = ops.gru_seq_fwd(g(gi), whh_g, bhh_g)
+    close(out, out_ref, atol=2e-5, rtol=1e-4)
+    dgi, dgh = ops.gru_seq_bwd(g(dout), saved, whh_g)
+    dgi_c, dgh_c = dgi.cpu(), dgh.cpu()
+    hprev = saved[:, :, :, 4, :].cpu()
+    for d in range(2):
+        a, c = dgi_c[:, :, d].reshape(-1, 3 * H), dgh_c[:, :, d].reshape(-1, 3 * H)
+        np.testing.assert_allclose((a.t() @ x.detach().reshape(-1, In)).numpy(), wih[d].grad.numpy(), atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose((c.t() @ hprev[:, :, d].reshape(-1, H)).numpy(), whh[d].grad.numpy(), atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose(a.sum(0).numpy(), bih[d].grad.numpy(), atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose(c.sum(0).numpy(), bhh[d].grad.numpy(), atol=2e-4, rtol=1e-3)
+    dx = sum(dgi_c[:, :, d] @ wih[d].detach() for d in range(2))
+    np.testing.assert_allclose(dx.numpy(), x.grad.numpy(), atol=2e-5, rtol=1e-3)
+
+
+def test_losses_vs_torch(ops):
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(7, 9, 1, generator=gen) * 3).requires_grad_(True)
+    t = (torch.rand(7, 9, 1, generator=gen) > 0.6).float()
+    ref = F.binary_cross_entropy_with_logits(x, t)
+    ref.backward()
+    loss, d, p = ops.loss_fwd_bwd(g(x.detach()), g(t), "bce")
+    assert abs(loss.item() - ref.item()) < 1e-6
+    close(d, x.grad, atol=1e-7, rtol=1e-4)
+    close(p, torch.sigmoid(x.detach()), atol=1e-6)
+    for red in ("mean", "sum"):
+        x.grad = None
+        pr = torch.sigmoid(x)
+        pt = torch.where(t == 1, pr, 1 - pr)
+        fl = -0.25 * (1 - pt) ** 2.0 * torch.log(pt + 1e-12)
+        fl = fl.mean() if red == "mean" else fl.sum()
+        fl.backward()
+        loss, d, _ = ops.loss_fwd_bwd(g(x.detach()), g(t), "focal", 0.25, 2.0, red)
+        assert abs(loss.item() - fl.item()) < 1e-5 * max(1.0, abs(fl.item()))
+        close(d, x.grad, atol=1e-6, rtol=1e-3)
+
+
+def test_adam_and_clip_vs_torch(ops):
+    gen = torch.Generator().manual_seed(4)
+    n = 10007
+    p0 = torch.randn(n, generator=gen)
+    for wd, max_norm in ((0.0, None), (1e-4, 1.0)):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pr], lr=1e-3, weight_decay=wd)
+        pg = g(torch.cat([p0, torch.zeros(1)]))[:n]          # arena view (aligned base)
+        m, v = torch.zeros_like(pg), torch.zeros_like(pg)
+        for step in range(1, 4):
+            grad = torch.randn(n, generator=gen) * (0.1 * step)
+            pr.grad = grad.clone()
+            if max_norm:
+                torch.nn.utils.clip_grad_norm_([pr], max_norm)
+            opt.step()
+            gg = g(torch.cat([grad, torch.zeros(1)]))
+            coef = None
+            if max_norm:
+                nc = ops.grad_norm_clip_coef(gg, max_norm)
+                assert abs(nc[0].item() - grad.norm().item()) < 1e-3
+                coef = nc[1:2]
+            ops.adam_step(pg, gg[:n], m, v, 1e-3, 0.9, 0.999, 1e-8, wd, step, coef)
+            close(pg, pr.detach(), atol=2e-6, rtol=1e-5)
+
+
+def test_logmel_vs_numpy_restatement(ops):
+    from oracle import logmel_ref
+    from sed_crnn_amd import feature
+    rng = np.random.RandomState(0)
+    n = 44100 // 2
+    tt = np.arange(n) / 44100.0
+    y = (0.3 * np.sin(2 * np.pi * 440 * tt) + 0.1 * np.sin(2 * np.pi * 3000 * tt) + 0.05 * rng.randn(n)).astype(np.float32)
+    for pad in ("constant", "reflect"):
+        ref = logmel_ref.mbe(y, pad_mode=pad)
+        out = feature.mbe(torch.from_numpy(y).cuda(), pad_mode=pad).cpu().numpy()
+        assert out.shape == ref.shape == (1 + n // 1024, 40)
+        np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4)
+    mu, sd = logmel_ref.standardize_fit(ref)
+    out = feature.mbe(torch.from_numpy(y).cuda(), pad_mode="reflect", mean=torch.from_numpy(mu).float().cuda(),
+                      std=torch.from_numpy(sd).float().cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, (ref - mu) / sd, atol=2e-3, rtol=1e-3)
