@@ -74,7 +74,10 @@ def test_g3_fit_loop_trajectory(sed):
     assert sc["er_overall_1sec"] == pytest.approx(float(d["val_er_1s"]), abs=1e-12)
     sd = m.state_dict()
     for k, v in _sd(d, "sd6.").items():
-        if v.dtype.is_floating_point:
+        # A conv bias in front of BatchNorm has an analytically ZERO gradient; what both the reference and this
+        # build see is rounding noise (~1e-9) that Adam normalises into +-lr steps, so those 8 numbers random-walk
+        # differently on any two implementations (and cannot change any output).  Everything else must agree.
+        if v.dtype.is_floating_point and not (k.startswith("convs.") and k.endswith(".bias")):
             _cmp(sd[k], v, atol=2e-3, rtol=5e-2, msg=k)
 
 
