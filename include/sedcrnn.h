@@ -137,9 +137,13 @@ int sed_linear_bwd(const float* x, const float* W, const float* y, float* dy, fl
 size_t sed_gru_seq_workspace_bytes(int H);          /* scratch for the transposed W_hh */
 int sed_gru_seq_fwd(const float* gi, const float* const* whh, const float* const* bhh,
                     float* out, float* saved, void* workspace, int B, int T, int H, void* stream);
-/* dout [B][T][2H] -> dgi [B][T][2][3H] (grad of gi) and dgh [B][T][2][3H] (grad of W_hh h + b_hh). */
+/* dout [B][T][2H] -> dgi [B][T][2][3H] (grad of gi) and dgh [B][T][2][3H] (grad of W_hh h + b_hh).
+ * dbih / dbhh (2 pointers each, or both NULL): bias gradients summed in-kernel (no re-read of dgi/dgh);
+ * workspace >= sed_gru_seq_bwd_workspace_bytes(B, H) when they are requested. */
+size_t sed_gru_seq_bwd_workspace_bytes(int B, int H);
 int sed_gru_seq_bwd(const float* dout, const float* saved, const float* const* whh,
-                    float* dgi, float* dgh, int B, int T, int H, void* stream);
+                    float* dgi, float* dgh, float* const* dbih, float* const* dbhh, void* workspace,
+                    int B, int T, int H, void* stream);
 
 /* ───────────── loss heads (sed.py:136,160; crnn_lightning.py:27-35) ─────────────
  * kind 0: BCEWithLogits mean; kind 1: focal (alpha, gamma, log(pt+1e-12)); reduction_mean=0 -> sum.

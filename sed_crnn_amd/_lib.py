@@ -67,7 +67,8 @@ SIGNATURES = {
     "sed_linear_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
     "sed_gru_seq_workspace_bytes": (_sz, [_i]),
     "sed_gru_seq_fwd": (_i, [_fp, _pp, _pp, _fp, _fp, _fp, _i, _i, _i, _stream]),
-    "sed_gru_seq_bwd": (_i, [_fp, _fp, _pp, _fp, _fp, _i, _i, _i, _stream]),
+    "sed_gru_seq_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "sed_gru_seq_bwd": (_i, [_fp, _fp, _pp, _fp, _fp, _pp, _pp, _fp, _i, _i, _i, _stream]),
     "sed_loss_fwd_bwd": (_i, [_fp, _fp, _i, _i, _f, _f, _i, _fp, _fp, _fp, _stream]),
     "sed_sigmoid": (_i, [_fp, _fp, _i, _stream]),
     "sed_sqnorm_workspace_bytes": (_sz, [_l]),

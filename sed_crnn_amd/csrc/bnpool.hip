@@ -20,11 +20,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_train_k(
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = sl; r < rows; r += 32) {
+    if (c < C) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+        int r = sl;
+        for (; r + 96 < rows; r += 128) {              // 8 independent loads in flight per thread
+            const float* p0 = part + (size_t)r * 2 * C + c;
+            a += (double)p0[0];                   q += (double)p0[C];
+            a1 += (double)p0[(size_t)64 * C];     q1 += (double)p0[(size_t)64 * C + C];
+            a2 += (double)p0[(size_t)128 * C];    q2 += (double)p0[(size_t)128 * C + C];
+            a3 += (double)p0[(size_t)192 * C];    q3 += (double)p0[(size_t)192 * C + C];
+        }
+        for (; r < rows; r += 32) {
             a += (double)part[(size_t)r * 2 * C + c];
             q += (double)part[(size_t)r * 2 * C + C + c];
         }
+        a += a1 + a2 + a3;
+        q += q1 + q2 + q3;
+    }
     s1[sl][cl] = a;
     s2[sl][cl] = q;
     __syncthreads();
@@ -84,8 +96,19 @@ __global__ __launch_bounds__(1024) void reduce_rows_k(const float* __restrict__ 
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0;
-    if (c < C)
-        for (int r = sl; r < rows; r += 32) a += (double)part[(size_t)r * row_stride + c];
+    if (c < C) {
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int r = sl;
+        for (; r + 96 < rows; r += 128) {
+            const float* p0 = part + (size_t)r * row_stride + c;
+            a += (double)p0[0];
+            a1 += (double)p0[(size_t)32 * row_stride];
+            a2 += (double)p0[(size_t)64 * row_stride];
+            a3 += (double)p0[(size_t)96 * row_stride];
+        }
+        for (; r < rows; r += 32) a += (double)part[(size_t)r * row_stride + c];
+        a += a1 + a2 + a3;
+    }
     s1[sl][cl] = a;
     __syncthreads();
     if (sl == 0 && c < C) {

@@ -17,6 +17,8 @@
 #define CV_CIC 32   // input channels per LDS chunk
 #define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
 #define CV_MTW 5    // max 32-row tiles per wave
+#define WG_NX 6      // wgrad: max float4 per thread of the halo tile   ((TT+2)*(F+2)*8 <= 256*WG_NX)
+#define WG_ND 10     // wgrad: max float4 per thread of the dY tile      (TT*F*32      <= 256*WG_ND)
 
 struct ConvPlan {
     int kind;       // 0 small, 1 mfma, -1 unsupported
@@ -344,6 +346,7 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
 // ───────────────────────── weight gradient ─────────────────────────
 struct WgradPlan {
     int kind;        // 0 small, 1 mfma
+    int db;          // mfma: double-buffered variant
     int TT, ntiles, ngroups, tblocks;
     size_t lds, slab_floats;
 };
@@ -357,6 +360,10 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
         if ((p.TT * F) % 2) p.kind = 0;
         p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
         if (p.lds > 150 * 1024) p.kind = 0;
+        else if (2 * p.lds <= 156 * 1024 && (p.TT + 2) * (F + 2) * 8 <= 256 * WG_NX && p.TT * F * 32 <= 256 * WG_ND) {
+            p.db = 1;
+            p.lds *= 2;
+        }
     }
     if (p.kind == 0) {
         p.TT = 4;
@@ -367,7 +374,9 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     }
     p.tblocks = cdiv(T, p.TT);
     p.ntiles = B * p.tblocks;
-    p.ngroups = p.ntiles < 128 ? p.ntiles : 128;
+    // mfma db: one resident block per CU at Cin=128; small (HBM-bound): enough blocks to fill every CU 4x
+    const int maxg = (p.kind == 1) ? (p.db ? 64 : 128) : 1024;
+    p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
     p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
     return p;
 }
@@ -434,31 +443,42 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_k(
     }
 }
 
-// small reduce: dw[co][ci][tap] = sum_g slabs[g][ci][tap][co]
-__global__ void conv_wgrad_reduce_small_k(const float* __restrict__ slabs, float* __restrict__ dw,
-                                          int ngroups, int Cin, int Cout) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int n = Cin * 9 * Cout;
-    if (i >= n) return;
-    int co = i % Cout, tap = (i / Cout) % 9, ci = i / (9 * Cout);
+// small reduce: dw[co][ci][tap] = sum_g slabs[g][ci][tap][co]; block = 32 outputs x 32 group slices
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                   int ngroups, int Cin, int Cout) {
+    __shared__ float s1[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int n = Cin * 9 * Cout;
+    const int i = blockIdx.x * 32 + cl;
     float a = 0.f;
-    for (int g = 0; g < ngroups; ++g) a += slabs[(size_t)g * n + i];
-    dw[((size_t)co * Cin + ci) * 9 + tap] = a;
+    if (i < n)
+        for (int g = sl; g < ngroups; g += 32) a += slabs[(size_t)g * n + i];
+    s1[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float A = 0.f;
+        for (int s = 0; s < 32; ++s) A += s1[s][cl];
+        int co = i % Cout, tap = (i / Cout) % 9, ci = i / (9 * Cout);
+        dw[((size_t)co * Cin + ci) * 9 + tap] = A;
+    }
 }
 
 // mfma: grid (ngroups, Cin/32, Cout/128); slabs [group][9][Cin][Cout]
+// D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions.
+// DB=true: both LDS tiles are double-buffered and the next tile's global loads are issued before the
+// MFMA loop of the current one (register prefetch, NX+ND float4 per thread), one barrier per tile.
+template <bool DB>
 __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
     int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = F + 2;
     const int HR = (TT + 2) * F2;
-    float* xh = smem;                 // [HR][32]
-    float* dys = smem + HR * 32;      // [TT*F][128]
+    const int MROWS = TT * F;
+    const int XH = HR * 32, DYS = MROWS * 128, BUF = XH + DYS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
-    const int MROWS = TT * F;
 
     f32x16 acc[9];
 #pragma unroll
@@ -466,40 +486,101 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x4 px[DB ? WG_NX : 1], pd[DB ? WG_ND : 1];
+    auto fetch = [&](int tile) {          // global -> registers
         int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
-        __syncthreads();
-        for (int i = tid; i < HR * 8; i += 256) {
-            int row = i >> 3, q = i & 7;
-            int tt = row / F2, ff = row - tt * F2;
-            int t = t0 + tt - 1, f = ff - 1;
-            f32x4 v = {0, 0, 0, 0};
-            if (t >= 0 && t < T && f >= 0 && f < F)
-                v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
-            *(f32x4*)(xh + row * 32 + q * 4) = v;
-        }
-        for (int i = tid; i < MROWS * 32; i += 256) {
-            int row = i >> 5, q = i & 31;
-            int tl = row / F, f = row - tl * F;
-            f32x4 v = {0, 0, 0, 0};
-            if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
-            *(f32x4*)(dys + row * 128 + q * 4) = v;
-        }
-        __syncthreads();
-        int tl = 0, f = h;            // position p = 2s + h
-        if (f >= F) { f -= F; tl = 1; }
-        for (int s = 0; s < MROWS / 2; ++s) {
-            const float* xp = xh + (tl * F2 + f) * 32 + r;
-            float bv = dys[(2 * s + h) * 128 + wave * 32 + r];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int u = 0; u < WG_NX; ++u) {
+            int i = tid + u * 256;
+            f32x4 v = {0, 0, 0, 0};
+            if (i < HR * 8) {
+                int row = i >> 3, q = i & 7;
+                int tt = row / F2, ff = row - tt * F2;
+                int t = t0 + tt - 1, f = ff - 1;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
+            }
+            px[u] = v;
+        }
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    float av = xp[(kw * F2 + kh) * 32];
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
-                }
-            f += 2;
-            if (f >= F) { f -= F; ++tl; }
+        for (int u = 0; u < WG_ND; ++u) {
+            int i = tid + u * 256;
+            f32x4 v = {0, 0, 0, 0};
+            if (i < MROWS * 32) {
+                int row = i >> 5, q = i & 31;
+                int tl = row / F, f = row - tl * F;
+                if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
+            }
+            pd[u] = v;
+        }
+    };
+    auto commit = [&](float* buf) {       // registers -> LDS
+#pragma unroll
+        for (int u = 0; u < WG_NX; ++u) {
+            int i = tid + u * 256;
+            if (i < HR * 8) *(f32x4*)(buf + i * 4) = px[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WG_ND; ++u) {
+            int i = tid + u * 256;
+            if (i < MROWS * 32) *(f32x4*)(buf + XH + i * 4) = pd[u];
+        }
+    };
+    auto compute = [&](const float* buf) {
+        const float* xh = buf;
+        const float* dys = buf + XH;
+        for (int tl = 0; tl < TT; ++tl) {
+            const float* xrow = xh + (tl * F2 + h) * 32 + r;
+            const float* drow = dys + (tl * F + h) * 128 + wave * 32 + r;
+#pragma unroll 4
+            for (int fs = 0; fs < F / 2; ++fs) {            // position p = tl*F + 2*fs + h
+                const float* xp = xrow + fs * 64;
+                float bv = drow[fs * 256];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        float av = xp[(kw * F2 + kh) * 32];
+                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    if (DB) {
+        int tile = blockIdx.x, cur = 0;
+        if (tile < ntiles) { fetch(tile); commit(smem); }
+        __syncthreads();
+        for (; tile < ntiles; tile += gridDim.x) {
+            const int nxt = tile + gridDim.x;
+            if (nxt < ntiles) fetch(nxt);
+            compute(smem + cur * BUF);
+            if (nxt < ntiles) commit(smem + (cur ^ 1) * BUF);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+            __syncthreads();
+            for (int i = tid; i < HR * 8; i += 256) {
+                int row = i >> 3, q = i & 7;
+                int tt = row / F2, ff = row - tt * F2;
+                int t = t0 + tt - 1, f = ff - 1;
+                f32x4 v = {0, 0, 0, 0};
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
+                *(f32x4*)(smem + i * 4) = v;
+            }
+            for (int i = tid; i < MROWS * 32; i += 256) {
+                int row = i >> 5, q = i & 31;
+                int tl = row / F, f = row - tl * F;
+                f32x4 v = {0, 0, 0, 0};
+                if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
+                *(f32x4*)(smem + XH + i * 4) = v;
+            }
+            __syncthreads();
+            compute(smem);
         }
     }
     // D rows = ci, cols = co
@@ -537,8 +618,14 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
     SedProfScope prof(p.kind == 1 ? SED_K_CONV_MFMA_WGRAD : SED_K_CONV_SMALL_WGRAD, s,
                       p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
     if (p.kind == 1) {
-        SED_TRY(set_lds(conv3x3_mfma_wgrad_k, p.lds));
-        conv3x3_mfma_wgrad_k<<<dim3(p.ngroups, Cin / 32, Cout / 128), 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        dim3 grid(p.ngroups, Cin / 32, Cout / 128);
+        if (p.db) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
+            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
+            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     } else {
@@ -546,7 +633,7 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
         SED_TRY(set_lds(conv3x3_small_wgrad_k, p.lds));
         conv3x3_small_wgrad_k<<<p.ngroups, 256, p.lds, s>>>(x, x_is_nchw, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
         SED_LAUNCH_CHECK("conv3x3_small_wgrad");
-        conv_wgrad_reduce_small_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+        conv_wgrad_reduce_small_k<<<cdiv(n, 32), 1024, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     }
     SED_LAUNCH_CHECK("conv3x3_wgrad_reduce");
     return 0;

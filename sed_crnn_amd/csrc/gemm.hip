@@ -6,10 +6,54 @@
 // fp32 in / fp32 accumulate: bit-for-bit a k-ordered fmaf chain, no reduced precision.
 #include "common.h"
 
-#define GM_BK 16
-#define GM_LDK 20   // k-contiguous LDS row: 16 + 4 pad floats -> conflict-free ds_read_b128
+#define GM_BK 32
+#define GM_LDK 36   // k-contiguous LDS row: 32 + 4 pad floats (16-B slot stride 9) -> conflict-free ds_read_b128
 
 // A_KC / B_KC: operand is contiguous along k (true) or along m/n (false).
+// Block tile (64*WM) x (64*WN), 4 waves as 2x2, each wave WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).
+// LDS tiles are double-buffered: the next K-step's global loads are issued before the MFMA block of the
+// current one and written to the other buffer after it; one barrier per K-step of 32.
+template <bool KC, int NR, int TILE>
+__device__ __forceinline__ void gm_load(f32x4* reg, const float* __restrict__ P, long s_mn, long s_k, int mn0, int MN,
+                                        int K, int vec, int k0, int tid) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        int i = tid + u * 256;
+        f32x4 v = {0, 0, 0, 0};
+        if (KC) {
+            int row = i >> 3, kq = i & 7;
+            int m = mn0 + row, k = k0 + kq * 4;
+            if (m < MN) {
+                const float* p = P + (long)m * s_mn + k;
+                if (vec && k + 3 < K) v = *(const f32x4*)p;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = p[e];
+            }
+        } else {
+            int kk = i / (TILE / 4), mq = i - kk * (TILE / 4);
+            int m = mn0 + mq * 4, k = k0 + kk;
+            if (k < K) {
+                const float* p = P + (long)k * s_k + m;
+                if (vec && m + 3 < MN) v = *(const f32x4*)p;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (m + e < MN) v[e] = p[e];
+            }
+        }
+        reg[u] = v;
+    }
+}
+template <bool KC, int NR, int TILE>
+__device__ __forceinline__ void gm_store(const f32x4* reg, float* S, int tid) {
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+        int i = tid + u * 256;
+        if (KC) { int row = i >> 3, kq = i & 7; *(f32x4*)(S + row * GM_LDK + kq * 4) = reg[u]; }
+        else { int kk = i / (TILE / 4), mq = i - kk * (TILE / 4); *(f32x4*)(S + kk * TILE + mq * 4) = reg[u]; }
+    }
+}
+
 template <int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_k(
     const float* __restrict__ A, long a_si, long a_sk, const float* __restrict__ Bm, long b_sk, long b_sj,
@@ -18,8 +62,10 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int A_FLOATS = A_KC ? BM * GM_LDK : GM_BK * BM;
     constexpr int B_FLOATS = B_KC ? BN * GM_LDK : GM_BK * BN;
-    __shared__ __attribute__((aligned(16))) float As[A_FLOATS];
-    __shared__ __attribute__((aligned(16))) float Bs[B_FLOATS];
+    constexpr int NA = 2 * WM, NB = 2 * WN;           // float4 per thread per K-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As0 = smem;                                // [2][A_FLOATS]
+    float* Bs0 = smem + 2 * A_FLOATS;                 // [2][B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -34,89 +80,23 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][u][j] = 0.f;
 
-    f32x4 ra[WM], rb[WN];
-    auto load_a = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < WM; ++u) {
-            int i = tid + u * 256;
-            f32x4 v = {0, 0, 0, 0};
-            if (A_KC) {
-                int row = i >> 2, kq = i & 3;
-                int m = m0 + row, k = k0 + kq * 4;
-                if (m < M) {
-                    const float* p = A + (long)m * a_si + k;
-                    if (a_vec && k + 3 < K) v = *(const f32x4*)p;
-                    else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = p[e];
-                }
-            } else {
-                int kk = i / (BM / 4), mq = i - kk * (BM / 4);
-                int m = m0 + mq * 4, k = k0 + kk;
-                if (k < K) {
-                    const float* p = A + (long)k * a_sk + m;
-                    if (a_vec && m + 3 < M) v = *(const f32x4*)p;
-                    else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (m + e < M) v[e] = p[e];
-                }
-            }
-            ra[u] = v;
-        }
-    };
-    auto load_b = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            int i = tid + u * 256;
-            f32x4 v = {0, 0, 0, 0};
-            if (B_KC) {
-                int row = i >> 2, kq = i & 3;
-                int n = n0 + row, k = k0 + kq * 4;
-                if (n < N) {
-                    const float* p = Bm + (long)n * b_sj + k;
-                    if (b_vec && k + 3 < K) v = *(const f32x4*)p;
-                    else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (k + e < K) v[e] = p[e];
-                }
-            } else {
-                int kk = i / (BN / 4), nq = i - kk * (BN / 4);
-                int n = n0 + nq * 4, k = k0 + kk;
-                if (k < K) {
-                    const float* p = Bm + (long)k * b_sk + n;
-                    if (b_vec && n + 3 < N) v = *(const f32x4*)p;
-                    else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) if (n + e < N) v[e] = p[e];
-                }
-            }
-            rb[u] = v;
-        }
-    };
-    auto store_ab = [&]() {
-#pragma unroll
-        for (int u = 0; u < WM; ++u) {
-            int i = tid + u * 256;
-            if (A_KC) { int row = i >> 2, kq = i & 3; *(f32x4*)(As + row * GM_LDK + kq * 4) = ra[u]; }
-            else { int kk = i / (BM / 4), mq = i - kk * (BM / 4); *(f32x4*)(As + kk * BM + mq * 4) = ra[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < WN; ++u) {
-            int i = tid + u * 256;
-            if (B_KC) { int row = i >> 2, kq = i & 3; *(f32x4*)(Bs + row * GM_LDK + kq * 4) = rb[u]; }
-            else { int kk = i / (BN / 4), nq = i - kk * (BN / 4); *(f32x4*)(Bs + kk * BN + nq * 4) = rb[u]; }
-        }
-    };
-
-    load_a(0);
-    load_b(0);
+    f32x4 ra[NA], rb[NB];
+    gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, 0, tid);
+    gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, 0, tid);
+    gm_store<A_KC, NA, BM>(ra, As0, tid);
+    gm_store<B_KC, NB, BN>(rb, Bs0, tid);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < K; k0 += GM_BK) {
-        __syncthreads();
-        store_ab();
-        __syncthreads();
-        if (k0 + GM_BK < K) { load_a(k0 + GM_BK); load_b(k0 + GM_BK); }
+        const bool more = k0 + GM_BK < K;
+        if (more) {
+            gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, k0 + GM_BK, tid);
+            gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, k0 + GM_BK, tid);
+        }
+        const float* As = As0 + cur * A_FLOATS;
+        const float* Bs = Bs0 + cur * B_FLOATS;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < GM_BK / 8; ++g) {
             f32x4 af[WM], bf[WN];
 #pragma unroll
             for (int t = 0; t < WM; ++t) {
@@ -140,6 +120,12 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
                     for (int u = 0; u < WN; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
         }
+        if (more) {
+            gm_store<A_KC, NA, BM>(ra, As0 + (cur ^ 1) * A_FLOATS, tid);
+            gm_store<B_KC, NB, BN>(rb, Bs0 + (cur ^ 1) * B_FLOATS, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 
 #pragma unroll
@@ -162,14 +148,28 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
         }
 }
 
+template <int WM, int WN, bool AKC, bool BKC>
+static int launch_gemm2(dim3 grid, hipStream_t s, const float* A, long a_si, long a_sk, const float* B, long b_sk,
+                        long b_sj, float* C, long ldc, const float* bias, float beta, int M, int N, int K, int av, int bv) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr size_t lds = 2 * ((AKC ? BM * GM_LDK : GM_BK * BM) + (BKC ? BN * GM_LDK : GM_BK * BN)) * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_k<WM, WN, AKC, BKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { sed_set_error("gemm_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    gemm_f32_k<WM, WN, AKC, BKC><<<grid, 256, lds, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    return 0;
+}
+
 template <int WM, int WN>
-static void launch_gemm(bool akc, bool bkc, dim3 grid, hipStream_t s, const float* A, long a_si, long a_sk,
-                        const float* B, long b_sk, long b_sj, float* C, long ldc, const float* bias, float beta,
-                        int M, int N, int K, int av, int bv) {
-    if (akc && bkc) gemm_f32_k<WM, WN, true, true><<<grid, 256, 0, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else if (akc && !bkc) gemm_f32_k<WM, WN, true, false><<<grid, 256, 0, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else if (!akc && bkc) gemm_f32_k<WM, WN, false, true><<<grid, 256, 0, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else gemm_f32_k<WM, WN, false, false><<<grid, 256, 0, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+static int launch_gemm(bool akc, bool bkc, hipStream_t s, const float* A, long a_si, long a_sk,
+                       const float* B, long b_sk, long b_sj, float* C, long ldc, const float* bias, float beta,
+                       int M, int N, int K, int av, int bv) {
+    dim3 grid(cdiv(N, 64 * WN), cdiv(M, 64 * WM));
+    if (akc && bkc) return launch_gemm2<WM, WN, true, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    if (akc && !bkc) return launch_gemm2<WM, WN, true, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    if (!akc && bkc) return launch_gemm2<WM, WN, false, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    return launch_gemm2<WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
 }
 
 extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
@@ -184,12 +184,15 @@ extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B
     int bv = (((uintptr_t)B & 15) == 0) && ((bkc ? b_sj : b_sk) % 4 == 0);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_GEMM, s, 2.0 * M * (double)N * K);
-    long blocks22 = (long)cdiv(M, 128) * cdiv(N, 128);
-    if (M > 64 && N > 64 && blocks22 >= 192) {
-        launch_gemm<2, 2>(akc, bkc, dim3(cdiv(N, 128), cdiv(M, 128)), s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    } else {
-        launch_gemm<1, 1>(akc, bkc, dim3(cdiv(N, 64), cdiv(M, 64)), s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    }
+    // largest tile that still gives the 256 CUs enough workgroups
+    const long fill = 160;
+    long b22 = (long)cdiv(M, 128) * cdiv(N, 128), b21 = (long)cdiv(M, 128) * cdiv(N, 64), b12 = (long)cdiv(M, 64) * cdiv(N, 128);
+    int rc;
+    if (M > 64 && N > 64 && b22 >= fill) rc = launch_gemm<2, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    else if (M > 64 && b21 >= fill && (b21 >= b12 || N <= 64)) rc = launch_gemm<2, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    else if (N > 64 && b12 >= fill) rc = launch_gemm<1, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    else rc = launch_gemm<1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    if (rc) return rc;
     SED_LAUNCH_CHECK("gemm_f32");
     return 0;
 }

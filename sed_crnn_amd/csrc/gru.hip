@@ -121,7 +121,8 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
 template <int HREG>
 __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ whh0,
-    const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, int B, int T, int H) {
+    const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bpart,
+    int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H3 = 3 * H;
     float* dgh_s = smem;                         // [BT][3H]
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     float dhc[GRU_BT];                           // direct part z*dh carried by the gate thread
 #pragma unroll
     for (int b = 0; b < GRU_BT; ++b) dhc[b] = 0.f;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;   // bias-gradient partial sums over this block's rows and steps
     __syncthreads();
 
     for (int s = 0; s < T; ++s) {
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
                     dgh[o] = dr_pre; dgh[o + H] = dz_pre; dgh[o + 2 * H] = dghn;
                 }
                 dhc[b] = carry;
+                sb0 += dr_pre; sb1 += dz_pre; sb2 += dn_pre; sb3 += dghn;
                 dgh_s[b * H3 + g] = dr_pre; dgh_s[b * H3 + H + g] = dz_pre; dgh_s[b * H3 + 2 * H + g] = dghn;
             }
         }
@@ -203,6 +206,25 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
         }
         __syncthreads();
     }
+    if (bpart && gate) {
+        float* bp = bpart + ((size_t)(blockIdx.x * 2 + dir) * 4) * H + g;
+        bp[0] = sb0; bp[H] = sb1; bp[2 * H] = sb2; bp[3 * H] = sb3;
+    }
+}
+
+// db_ih = (sum dr, sum dz, sum dn_pre), db_hh = (sum dr, sum dz, sum d(gh_n)); partials summed in block order
+__global__ void gru_bias_grad_k(const float* __restrict__ bpart, int nblk, int H, float* __restrict__ dbih0,
+                                float* __restrict__ dbih1, float* __restrict__ dbhh0, float* __restrict__ dbhh1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * 4 * H) return;
+    int j = i % H, c = (i / H) % 4, dir = i / (4 * H);
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += bpart[((size_t)(b * 2 + dir) * 4 + c) * H + j];
+    float* dbih = dir ? dbih1 : dbih0;
+    float* dbhh = dir ? dbhh1 : dbhh0;
+    if (c < 3) dbih[c * H + j] = a;
+    if (c < 2) dbhh[c * H + j] = a;
+    if (c == 3) dbhh[2 * H + j] = a;
 }
 
 static int gru_threads(int H) { return ((3 * H + 63) / 64) * 64; }
@@ -237,16 +259,26 @@ extern "C" int sed_gru_seq_fwd(const float* gi, const float* const* whh, const f
     return 0;
 }
 
+extern "C" size_t sed_gru_seq_bwd_workspace_bytes(int B, int H) { return (size_t)cdiv(B, GRU_BT) * 2 * 4 * H * sizeof(float); }
+
 extern "C" int sed_gru_seq_bwd(const float* dout, const float* saved, const float* const* whh, float* dgi,
-                               float* dgh, int B, int T, int H, void* stream) {
+                               float* dgh, float* const* dbih, float* const* dbhh, void* workspace, int B, int T,
+                               int H, void* stream) {
     SED_REQUIRE(dout && saved && whh && whh[0] && whh[1] && dgi && dgh, "gru_seq_bwd: null pointer");
+    const bool want_bias = dbih && dbhh;
+    SED_REQUIRE(!want_bias || (workspace && dbih[0] && dbih[1] && dbhh[0] && dbhh[1]), "gru_seq_bwd: bias gradients need all four outputs and a workspace");
+    float* bpart = want_bias ? (float*)workspace : nullptr;
     SED_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && 3 * H <= 1024, "gru_seq_bwd: H=%d must be a multiple of 4 and <= 341", H);
     hipStream_t s = as_stream(stream);
     dim3 grid(cdiv(B, GRU_BT), 2);
     int nt = gru_threads(H);
     size_t lds = (size_t)GRU_BT * 6 * H * sizeof(float);
     SedProfScope prof(SED_K_GRU_BWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
-    GRU_DISPATCH(gru_seq_bwd_k, dout, saved, whh[0], whh[1], dgi, dgh, B, T, H);
+    GRU_DISPATCH(gru_seq_bwd_k, dout, saved, whh[0], whh[1], dgi, dgh, bpart, B, T, H);
     SED_LAUNCH_CHECK("gru_seq_bwd");
+    if (want_bias) {
+        gru_bias_grad_k<<<cdiv(8 * H, 256), 256, 0, s>>>(bpart, cdiv(B, GRU_BT), H, dbih[0], dbih[1], dbhh[0], dbhh[1]);
+        SED_LAUNCH_CHECK("gru_bias_grad");
+    }
     return 0;
 }

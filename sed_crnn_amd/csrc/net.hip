@@ -24,7 +24,7 @@ struct Layout {
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
-    size_t bn_part, sum_g, sum_gx, dbias_part, dconv, gradA, wgrad_ws, dgi, dgh, dgout[SED_MAX_GRU];
+    size_t bn_part, sum_g, sum_gx, dbias_part, dconv, gradA, wgrad_ws, dgi, dgh, gru_bws, dgout[SED_MAX_GRU];
     size_t dact[SED_MAX_DENSE], lin_ws;
     size_t total;     // floats
 };
@@ -107,6 +107,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->wgrad_ws = cv.take(max_wgrad);
         L->dgi = cv.take(M * 6 * maxH);
         L->dgh = cv.take(M * 6 * maxH);
+        L->gru_bws = cv.take(sed_gru_seq_bwd_workspace_bytes(c->B, maxH) / sizeof(float));
         for (int i = 0; i < c->n_gru; ++i) L->dgout[i] = cv.take(M * 2 * c->H[i]);
         for (int j = 0; j < c->n_dense - 1; ++j) L->dact[j] = cv.take(M * c->D[j]);
         L->lin_ws = cv.take(max_lin_ws);
@@ -166,11 +167,17 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
     const float* gin = ws + L.pooled[L.n_conv - 1];          // [M][C*F'] in the reference feature order
     for (int i = 0; i < L.n_gru; ++i) {
         const int H = L.gr[i].H, K = L.gr[i].in;
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < 2; ++d)
             SED_REQUIRE(p->gru_wih[i][d] && p->gru_whh[i][d] && p->gru_bih[i][d] && p->gru_bhh[i][d],
                         "net_forward: missing parameters of GRU layer %d dir %d", i, d);
-            SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
-                                 p->gru_bih[i][d], 0.f, M, 3 * H, K, stream));
+        // both directions in ONE GEMM (N = 6H) when their weights/biases are adjacent (the flat arena lays them so)
+        const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K && p->gru_bih[i][1] == p->gru_bih[i][0] + 3 * H;
+        if (fused) {
+            SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][0], 1, K, ws + L.gi[i], 6 * H, p->gru_bih[i][0], 0.f, M, 6 * H, K, stream));
+        } else {
+            for (int d = 0; d < 2; ++d)
+                SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
+                                     p->gru_bih[i][d], 0.f, M, 3 * H, K, stream));
         }
         const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
         const float* bhh[2] = {p->gru_bhh[i][0], p->gru_bhh[i][1]};
@@ -220,19 +227,26 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
             float* dgi = ws + L.dgi;
             float* dgh = ws + L.dgh;
-            SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, B, L.Tp, H, stream));
-            for (int d = 0; d < 2; ++d) {
+            for (int d = 0; d < 2; ++d)
                 SED_REQUIRE(g->gru_wih[i][d] && g->gru_whh[i][d] && g->gru_bih[i][d] && g->gru_bhh[i][d],
                             "net_backward: missing gradient buffers of GRU layer %d dir %d", i, d);
-                // dW_hh = dgh^T h_prev ; dW_ih = dgi^T x
+            float* dbih[2] = {g->gru_bih[i][0], g->gru_bih[i][1]};
+            float* dbhh[2] = {g->gru_bhh[i][0], g->gru_bhh[i][1]};
+            SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, dbih, dbhh, ws + L.gru_bws, B, L.Tp, H, stream));
+            for (int d = 0; d < 2; ++d)      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
                 SED_TRY(sed_gemm_f32(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
                                      g->gru_whh[i][d], H, nullptr, 0.f, 3 * H, H, M, stream));
-                SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
-                SED_TRY(sed_reduce_rows(dgh + d * 3 * H, M, 3 * H, 6 * H, g->gru_bhh[i][d], stream));
-                SED_TRY(sed_reduce_rows(dgi + d * 3 * H, M, 3 * H, 6 * H, g->gru_bih[i][d], stream));
-                // dx += dgi W_ih
-                SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 6 * H, 1, p->gru_wih[i][d], K, 1, dxin, K, nullptr, d ? 1.f : 0.f,
-                                     M, K, 3 * H, stream));
+            const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
+                               g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
+            if (fused) {                     // both directions at once: dW_ih = dgi^T x (M = 6H), dx = dgi W_ih (K = 6H)
+                SED_TRY(sed_gemm_f32(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, nullptr, 0.f, 6 * H, K, M, stream));
+                SED_TRY(sed_gemm_f32(dgi, 6 * H, 1, p->gru_wih[i][0], K, 1, dxin, K, nullptr, 0.f, M, K, 6 * H, stream));
+            } else {
+                for (int d = 0; d < 2; ++d) {
+                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
+                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 6 * H, 1, p->gru_wih[i][d], K, 1, dxin, K, nullptr, d ? 1.f : 0.f,
+                                         M, K, 3 * H, stream));
+                }
             }
         }
     }

@@ -152,9 +152,9 @@ class HipCRNN(nn.Module):
         order = []
         for j in range(len(self.dense)):
             order += [r["dense_w"][j], r["dense_b"][j]]
-        for i in range(len(self.gru_hidden)):
-            for d in range(2):
-                order += [r["gru_wih"][i][d], r["gru_whh"][i][d], r["gru_bih"][i][d], r["gru_bhh"][i][d]]
+        for i in range(len(self.gru_hidden)):          # the two directions of each tensor adjacent: one GEMM for both
+            for role in ("gru_wih", "gru_whh", "gru_bih", "gru_bhh"):
+                order += [r[role][i][0], r[role][i][1]]
         stage_ends = []
         off = 0
         offs = []

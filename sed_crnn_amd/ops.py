@@ -151,14 +151,21 @@ def gru_seq_fwd(gi, whh, bhh, save=True):
     return out, saved
 
 
-def gru_seq_bwd(dout, saved, whh):
+def gru_seq_bwd(dout, saved, whh, want_bias=False):
     B, T, H2 = dout.shape
     H = H2 // 2
     dgi = torch.empty(B, T, 2, 3 * H, device=dout.device)
     dgh = torch.empty(B, T, 2, 3 * H, device=dout.device)
-    check(lib().sed_gru_seq_bwd(ptr(_f32c(dout)), ptr(saved), _pp(whh), ptr(dgi), ptr(dgh), B, T, H, stream_ptr()),
-          "gru_seq_bwd")
-    return dgi, dgh
+    if not want_bias:
+        check(lib().sed_gru_seq_bwd(ptr(_f32c(dout)), ptr(saved), _pp(whh), ptr(dgi), ptr(dgh), None, None, None,
+                                    B, T, H, stream_ptr()), "gru_seq_bwd")
+        return dgi, dgh
+    dbih = [torch.empty(3 * H, device=dout.device) for _ in range(2)]
+    dbhh = [torch.empty(3 * H, device=dout.device) for _ in range(2)]
+    ws = torch.empty(lib().sed_gru_seq_bwd_workspace_bytes(B, H) // 4 + 1, device=dout.device)
+    check(lib().sed_gru_seq_bwd(ptr(_f32c(dout)), ptr(saved), _pp(whh), ptr(dgi), ptr(dgh), _pp(dbih), _pp(dbhh),
+                                ptr(ws), B, T, H, stream_ptr()), "gru_seq_bwd")
+    return dgi, dgh, dbih, dbhh
 
 
 def loss_fwd_bwd(logits, targets, kind="bce", alpha=0.25, gamma=2.0, reduction="mean"):

@@ -211,7 +211,12 @@ def test_gru_recurrence_fwd_bwd(ops, B, T, H):
     whh_g, bhh_g = [g(w.detach()) for w in whh], [g(b.detach()) for b in bhh]
     out, saved = ops.gru_seq_fwd(g(gi), whh_g, bhh_g)
     close(out, out_ref, atol=2e-5, rtol=1e-4)
-    dgi, dgh = ops.gru_seq_bwd(g(dout), saved, whh_g)
+    dgi, dgh, dbih, dbhh = ops.gru_seq_bwd(g(dout), saved, whh_g, want_bias=True)
+    dgi2, dgh2 = ops.gru_seq_bwd(g(dout), saved, whh_g)
+    assert torch.equal(dgi, dgi2) and torch.equal(dgh, dgh2)
+    for d in range(2):
+        np.testing.assert_allclose(dbih[d].cpu().numpy(), bih[d].grad.numpy(), atol=2e-4, rtol=1e-3)
+        np.testing.assert_allclose(dbhh[d].cpu().numpy(), bhh[d].grad.numpy(), atol=2e-4, rtol=1e-3)
     dgi_c, dgh_c = dgi.cpu(), dgh.cpu()
     hprev = saved[:, :, :, 4, :].cpu()
     for d in range(2):
