@@ -111,12 +111,43 @@ int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const flo
 /* out[c] = sum_r partials[r][c] in row order (double accumulation). */
 int sed_reduce_rows(const float* partials, int rows, int C, int row_stride, float* out, void* stream);
 
+/* ───────────── fused first conv block (conv recomputed, never stored; Cin <= 2) ─────────────
+ * The first block of the stack (sed.py:86-92,106-107, ch = 1) expands a few MB of input into the largest tensor of
+ * the step.  These four entries replace sed_conv3x3_fwd + the bn_* entries + sed_conv3x3_wgrad for block 1 and
+ * recompute conv(x) on the fly, so that tensor never exists in HBM.  x [B][Cin][F][T] (network input layout),
+ * wp = [9][C][Cin] from sed_conv3x3_pack_weights, pooled output / dout channels-last [B][T/pt][F/pf][C].
+ * rows = sed_conv1_fused_rows(B,T) partial rows for stats ([rows][2][C]) and bwd_reduce ([rows][2][C]). */
+int sed_conv1_fused_supported(int Cin, int F, int T, int C, int pool_f, int pool_t);   /* 1 = shapes accepted */
+int sed_conv1_fused_rows(int B, int T);
+int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials,
+                    int B, int Cin, int F, int T, int C, void* stream);
+int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
+                                    const float* shift, float* out, int B, int Cin, int F, int T, int C,
+                                    int pool_f, int pool_t, float drop_p, uint64_t seed, void* stream);
+int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
+                         const float* scale, const float* shift, const float* mean, const float* rstd,
+                         float* partials, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
+                         float drop_p, uint64_t seed, void* stream);
+size_t sed_conv1_bwd_apply_workspace_bytes(int B, int Cin, int T, int C);
+/* dy is formed on the fly: writes dw_oihw [C][Cin][3][3] and the conv-bias gradient only. */
+int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias, const float* dout,
+                              const float* scale, const float* shift, const float* mean, const float* rstd,
+                              const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
+                              void* workspace, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
+                              float drop_p, uint64_t seed, void* stream);
+
 /* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
  * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.
  * A(i,k) = A[i*a_si + k*a_sk], B(k,j) = B[k*b_sk + j*b_sj]; for each operand one of the
  * two strides must be 1.  Exact fp32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
 int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
                  float* C, long ldc, const float* bias, float beta, int M, int N, int K, void* stream);
+/* Same product (no bias, beta = 0) with an optional scratch buffer: small-output / long-K shapes (the GRU
+ * weight gradients, M*N small, K = B*T') are split along K into fixed slices and summed in slice order
+ * (deterministic).  workspace >= sed_gemm_f32_workspace_bytes(M,N,K) (0 = the shape is not split). */
+size_t sed_gemm_f32_workspace_bytes(int M, int N, int K);
+int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
+                    float* C, long ldc, int M, int N, int K, void* workspace, void* stream);
 
 /* Small dense layer y = act(x W^T + b) for the time-distributed head (sed.py:103,112;
  * crnn_lightning.py:63-64,72-73). x [M][K], W [N][K], y [M][N]; relu=1 applies ReLU. */

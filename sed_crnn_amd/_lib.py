@@ -53,6 +53,13 @@ SIGNATURES = {
     "sed_conv3x3_fwd": (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_wgrad": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv1_fused_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sed_conv1_fused_rows": (_i, [_i, _i]),
+    "sed_conv1_stats": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv1_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_conv1_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_conv1_bwd_apply_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
     "sed_bn_finalize_train": (_i, [_fp, _i, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
     "sed_bn_finalize_eval": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _stream]),
     "sed_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
@@ -62,6 +69,8 @@ SIGNATURES = {
     "sed_bn_relu_pool_drop_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
     "sed_reduce_rows": (_i, [_fp, _i, _i, _i, _fp, _stream]),
     "sed_gemm_f32": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _fp, _f, _i, _i, _i, _stream]),
+    "sed_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sed_gemm_f32_ws": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _i, _i, _i, _fp, _stream]),
     "sed_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
     "sed_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "sed_linear_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),

@@ -12,6 +12,7 @@
 //              channels in LDS read with conflict-free ds_read_b128, weights double-buffered.
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
+#include <stdlib.h>
 #include "common.h"
 
 #define CV_CIC 32   // input channels per LDS chunk
@@ -20,7 +21,10 @@
 #define WG_NX 6      // wgrad: max float4 per thread of the halo tile   ((TT+2)*(F+2)*8 <= 256*WG_NX)
 #define WG_ND 10     // wgrad: max float4 per thread of the dY tile      (TT*F*32      <= 256*WG_ND)
 
+#define CV_NH 8      // fwd v2: max float4 per thread of the halo tile ((TT+2)*(F+2)*8 <= 256*CV_NH)
+
 struct ConvPlan {
+    int v2;         // mfma: register-streamed weights + double-buffered halo
     int kind;       // 0 small, 1 mfma, -1 unsupported
     int TT;         // time rows per block tile
     int nct;        // mfma: 32-wide co tiles per block
@@ -42,6 +46,12 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
             if (TT > 8) TT = 8;
             p.kind = 1; p.TT = TT; p.nct = nct;
             p.lds = ((size_t)(TT + 2) * (F + 2) * CV_LD + 2 * 32 * nct * CV_LD) * sizeof(float);
+            if ((TT + 2) * (F + 2) * 8 <= 256 * CV_NH) {
+                p.v2 = 1;
+                p.lds = (size_t)2 * (TT + 2) * (F + 2) * CV_LD * sizeof(float);
+            }
+        } else {
+            return p;     // MFMA-sized channels but a mel axis wider than one block tile: unsupported
         }
     }
     if (p.kind < 0) {
@@ -60,6 +70,14 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
 }
 
 // ───────────────────────── weight packing ─────────────────────────
+// MFMA fragment order of a (Cin -> Cout) tap matrix: [tap][ci/32][ (ci%32)/8 ][co/32][lane = co%32 + 32*((ci%8)/4)][ci%4]
+// i.e. exactly the B operand of v_mfma_f32_32x32x2_f32 for 4 consecutive k-steps, 1 KiB per wave-load.
+__host__ __device__ inline size_t conv_frag_index(int tap, int co, int ci, int Cout, int Cin) {
+    int cc = ci >> 5, g = (ci & 31) >> 3, h = (ci & 7) >> 2, j = ci & 3;
+    int cot = co >> 5, r = co & 31;
+    return ((((((size_t)tap * (Cin >> 5) + cc) * 4 + g) * (Cout >> 5) + cot) * 64) + r + 32 * h) * 4 + j;
+}
+
 __global__ void conv_pack_w_k(const float* __restrict__ w, float* __restrict__ wf,
                               float* __restrict__ wd, int Cout, int Cin) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,9 +85,10 @@ __global__ void conv_pack_w_k(const float* __restrict__ w, float* __restrict__ w
     if (i >= n) return;
     int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
     float v = w[i];
-    if (wf) wf[((size_t)tap * Cout + co) * Cin + ci] = v;
-    // dgrad: dx[pos][ci] = sum_tap' sum_co dy[pos + tap' - 1][co] * w[co][ci][flip(tap')]
-    if (wd) wd[((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+    const bool frag = (Cin % 32 == 0) && (Cout % 32 == 0);
+    if (wf) wf[frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
+    // dgrad: dx[pos][ci] = sum_tap' sum_co dy[pos + tap' - 1][co] * w[co][ci][flip(tap')]  (a Cout -> Cin conv)
+    if (wd) wd[frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
 }
 
 extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Cout, int Cin, void* stream) {
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
 #pragma unroll
         for (int u = 0; u < WV4; ++u) {
             int i = tid + u * 256, row = i >> 3, q = i & 7;
-            f32x4 v = *(const f32x4*)(wp + ((size_t)(0 * Cout + co0 + row)) * Cin + cc * CV_CIC + q * 4);
+            f32x4 v = *(const f32x4*)(wp + conv_frag_index(0, co0 + row, cc * CV_CIC + q * 4, Cout, Cin));
             *(f32x4*)(wbuf + row * CV_LD + q * 4) = v;
         }
         __syncthreads();
@@ -226,7 +245,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
 #pragma unroll
                 for (int u = 0; u < WV4; ++u) {
                     int i = tid + u * 256, row = i >> 3, q = i & 7;
-                    wn[u] = *(const f32x4*)(wp + ((size_t)((tap + 1) * Cout + co0 + row)) * Cin + cc * CV_CIC + q * 4);
+                    wn[u] = *(const f32x4*)(wp + conv_frag_index(tap + 1, co0 + row, cc * CV_CIC + q * 4, Cout, Cin));
                 }
             }
             const int kh = tap / 3, kw = tap - kh * 3;
@@ -299,6 +318,146 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
     }
 }
 
+// ── v2: weights streamed L2 -> registers in fragment order (one coalesced 1 KiB load per wave and k-group, no LDS,
+// no per-tap barrier), halo tile double-buffered in LDS with the next chunk's global loads issued before the
+// MFMA loop of the current one: one barrier per 32-channel chunk (4 per block instead of 40).
+template <int NCT, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int dbg) {
+    constexpr int MPARTS = 4 / NCT;
+    constexpr int WROWS = 32 * NCT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    const int HR = (TT + 2) * F2;
+    const int HB = HR * CV_LD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
+    const int ct = wave % NCT, mp = wave / NCT;
+    const int MROWS = TT * F;
+    const int nMT = (MROWS + 31) >> 5;
+    const int nchunks = Cin / CV_CIC, ncot = Cout >> 5, cot = blockIdx.z * NCT + ct;
+
+    int abase[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int p = (mp + i * MPARTS) * 32 + r;
+        if (p >= MROWS) p = MROWS - 1;
+        int tl = p / F, f = p - tl * F;
+        abase[i] = (tl * F2 + f) * CV_LD + 4 * h;
+    }
+    f32x16 acc[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    f32x4 ph[CV_NH];
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            int i = tid + u * 256;
+            f32x4 v = {0, 0, 0, 0};
+            if (i < HR * 8) {
+                int row = i >> 3, q = i & 7;
+                int tt = row / F2, ff = row - tt * F2;
+                int t = t0 + tt - 1, f = ff - 1;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
+            }
+            ph[u] = v;
+        }
+    };
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            int i = tid + u * 256;
+            if (i < HR * 8) *(f32x4*)(buf + (i >> 3) * CV_LD + (i & 7) * 4) = ph[u];
+        }
+    };
+    const f32x4* wl = (const f32x4*)wq + (size_t)cot * 64 + lane;
+    auto load_b = [&](f32x4* bq, int cc, int tap) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = wl[(((size_t)tap * nchunks + cc) * 4 + g) * ncot * 64];
+    };
+
+    fetch(0);
+    commit(smem);
+    f32x4 bf[4];
+    load_b(bf, 0, 0);
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bool more = cc + 1 < nchunks;
+        if (more) fetch(cc + 1);
+        const float* halo = smem + (cc & 1) * HB;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x4 bn[4];
+            if (tap < 8) load_b(bn, cc, tap + 1);
+            else if (more) load_b(bn, cc + 1, 0);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = (kw * F2 + kh) * CV_LD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 af[CV_MTW];
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i)
+                    af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < CV_MTW; ++i)
+                        if (mp + i * MPARTS < nMT)
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[g][j], acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[g] = bn[g];
+        }
+        if (more) commit(smem + ((cc + 1) & 1) * HB);
+        __syncthreads();
+    }
+
+    const int co = co0 + ct * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int mt = mp + i * MPARTS;
+        if (mt < nMT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                int p = mt * 32 + row;
+                int tl = p / F, f = p - tl * F;
+                if (p < MROWS && t0 + tl < T) {
+                    float v = acc[i][j] + bv;
+                    if (!(dbg & 1)) y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+    }
+    if (stat && !(dbg & 2)) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* red = smem;                          // [4 waves][2][32]; the last loop barrier already passed
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        if (tid < 2 * WROWS) {
+            int which = tid / WROWS, c = tid - which * WROWS;
+            int cti = c >> 5, cr = c & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
 extern "C" int sed_conv3x3_stat_rows(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
     ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
     return p.kind >= 0 ? p.rows : 0;
@@ -328,7 +487,24 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
         dim3 grid(p.tblocks, B, Cout / (32 * p.nct));
-        if (p.nct == 4) {
+        static const int variant = getenv("SED_CONV_VARIANT") ? atoi(getenv("SED_CONV_VARIANT")) : 2;   // tuning knob
+        static const int dbg = getenv("SED_CONV_DEBUG") ? atoi(getenv("SED_CONV_DEBUG")) : 0;            // timing-only ablations
+        if (p.v2 && variant >= 1) {
+            if (p.nct == 4 && variant == 1) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 1>), p.lds));
+                conv3x3_mfma_fwd2_k<4, 1><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+            } else if (p.nct == 4) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
+                conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+            } else if (p.nct == 2) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
+                conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+            } else {
+                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
+                conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+            }
+        } else if (p.nct == 4) {
+            p.lds = ((size_t)(p.TT + 2) * (F + 2) * CV_LD + 2 * 32 * p.nct * CV_LD) * sizeof(float);
             SED_TRY(set_lds(conv3x3_mfma_fwd_k<4>, p.lds));
             conv3x3_mfma_fwd_k<4><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
         } else if (p.nct == 2) {
@@ -529,20 +705,34 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     auto compute = [&](const float* buf) {
         const float* xh = buf;
         const float* dys = buf + XH;
+        // one wave per SIMD: the LDS operands of k-step fs+1 are read while the 9 MFMAs of step fs issue
+        // (explicit two-stage register pipeline; position p = tl*F + 2*fs + h)
+        const int nfs = F >> 1;
         for (int tl = 0; tl < TT; ++tl) {
             const float* xrow = xh + (tl * F2 + h) * 32 + r;
             const float* drow = dys + (tl * F + h) * 128 + wave * 32 + r;
-#pragma unroll 4
-            for (int fs = 0; fs < F / 2; ++fs) {            // position p = tl*F + 2*fs + h
+            float a0[9], a1[9], b0, b1;
+            auto ld = [&](int fs, float* a, float& bq) {
                 const float* xp = xrow + fs * 64;
-                float bv = drow[fs * 256];
+                bq = drow[fs * 256];
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        float av = xp[(kw * F2 + kh) * 32];
-                        acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[kh * 3 + kw], 0, 0, 0);
-                    }
+                    for (int kw = 0; kw < 3; ++kw) a[kh * 3 + kw] = xp[(kw * F2 + kh) * 32];
+            };
+            ld(0, a0, b0);
+            int fs = 0;
+            for (; fs + 1 < nfs; fs += 2) {
+                ld(fs + 1, a1, b1);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0, acc[k], 0, 0, 0);
+                if (fs + 2 < nfs) ld(fs + 2, a0, b0);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k], b1, acc[k], 0, 0, 0);
+            }
+            if (fs < nfs) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0, acc[k], 0, 0, 0);
             }
         }
     };

@@ -1,0 +1,327 @@
+// conv1.hip — first conv block with the convolution RECOMPUTED instead of stored.
+//
+// Block 1 of the reference stack (sed.py:88-92,106-107 with ch = 1 at sed.py:86) turns a 5 MB input into a
+// 671 MB conv output (config 2) whose only readers are BatchNorm's statistics, the normalise/ReLU/pool pass and
+// their backward.  With Cin <= 2 one output costs 9..18 FMAs, far less than moving it through HBM, so none of the
+// four passes materialises it: each recomputes conv(x) from the L2-resident input tile in LDS.
+//   A  stats      : sum / sum^2 partials                         (reads x)
+//   B  fwd        : BN scale/shift + ReLU + max-pool + dropout    (reads x, writes pooled)
+//   C  bwd reduce : sum g, sum g*xhat                             (reads x, dpooled)
+//   D  bwd apply  : dy on the fly -> dW (9*Cin taps), dbias       (reads x, dpooled; dy is never written;
+//                                                                   the network input needs no data gradient)
+// HBM traffic of block 1 drops from ~5.0 GB to ~1.0 GB per step at config 2.  Same arithmetic order in all four
+// passes, so the recomputed values are bit-identical between passes; fixed-order two-stage reductions.
+#include "common.h"
+
+#define C1_TT 4
+#define C1_MAXBLOCKS 2048
+
+template <int CIN>
+struct C1W { f32x4 w[9 * CIN]; f32x4 b; };
+
+template <int CIN>
+__device__ __forceinline__ void c1_load_w(C1W<CIN>& W, const float* __restrict__ wp, const float* __restrict__ bias,
+                                          int Cout, int cg) {
+    // wp [9][Cout][Cin]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W.w[tap * CIN + ci][k] = wp[((size_t)tap * Cout + cg * 4 + k) * CIN + ci];
+    W.b = bias ? *(const f32x4*)(bias + cg * 4) : (f32x4){0, 0, 0, 0};
+}
+
+template <int CIN>
+__device__ __forceinline__ f32x4 c1_conv(const C1W<CIN>& W, const float* __restrict__ halo, int tl, int f, int F2) {
+    f32x4 acc = W.b;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float* hp = halo + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc += hp[ci] * W.w[(kh * 3 + kw) * CIN + ci];
+        }
+    return acc;
+}
+
+template <int CIN>
+__device__ __forceinline__ void c1_stage(float* halo, const float* __restrict__ x, int b, int t0, int F, int T) {
+    const int F2 = F + 2;
+    const int n = (C1_TT + 2) * F2 * CIN;
+    for (int i = threadIdx.x; i < n; i += 256) {          // time fastest: contiguous in the NCHW input
+        int tt = i % (C1_TT + 2), ff = (i / (C1_TT + 2)) % F2, ci = i / ((C1_TT + 2) * F2);
+        int t = t0 + tt - 1, f = ff - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * CIN + ci) * F + f) * T + t];
+        halo[(tt * F2 + ff) * CIN + ci] = v;
+    }
+}
+
+// MODE 0: stats  1: forward  2: backward reduce  3: backward apply + weight gradient
+template <int CIN, int MODE>
+__global__ __launch_bounds__(256) void conv1_fused_k(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+    const float* __restrict__ dout, float* __restrict__ out, float* __restrict__ partials,
+    int B, int F, int T, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    float* halo = smem;                                       // [(TT+2)][F2][CIN]
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2, nslots = 256 / C4;
+    const int cg = tid % C4, slot = tid / C4;
+    const bool active = slot < nslots;
+    const int tblocks = (T + C1_TT - 1) / C1_TT, ntiles = B * tblocks;
+    const int Tp = T / pt, Fp = F / pf;
+    const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float invN = 1.f / ((float)B * (float)T * (float)F);
+
+    C1W<CIN> W;
+    if (active) c1_load_w<CIN>(W, wp, bias, C, cg);
+    f32x4 sc = {0, 0, 0, 0}, sh = sc, mu = sc, rs = sc, sg = sc, sgx = sc;
+    if (active && MODE >= 1) {
+        sc = *(const f32x4*)(scale + cg * 4);
+        sh = *(const f32x4*)(shift + cg * 4);
+        if (MODE >= 2) { mu = *(const f32x4*)(mean + cg * 4); rs = *(const f32x4*)(rstd + cg * 4); }
+        if (MODE == 3) { sg = *(const f32x4*)(sum_g + cg * 4) * invN; sgx = *(const f32x4*)(sum_gx + cg * 4) * invN; }
+    }
+    f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};              // stats / (sum g, sum g xhat) / dbias
+    f32x4 dw[MODE == 3 ? 9 * CIN : 1];
+    if (MODE == 3) {
+#pragma unroll
+        for (int k = 0; k < 9 * CIN; ++k) dw[k] = (f32x4){0, 0, 0, 0};
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tblocks, t0 = (tile - b * tblocks) * C1_TT;
+        __syncthreads();
+        c1_stage<CIN>(halo, x, b, t0, F, T);
+        __syncthreads();
+        if (!active) continue;
+        if (MODE == 0) {
+            for (int p = slot; p < C1_TT * F; p += nslots) {
+                int tl = p / F, f = p - tl * F;
+                if (t0 + tl >= T) break;
+                f32x4 v = c1_conv<CIN>(W, halo, tl, f, F2);
+                a1 += v;
+                a2 += v * v;
+            }
+        } else {
+            const int tpn = C1_TT / pt;                          // pooled rows in this tile (pt divides TT)
+            for (int op = slot; op < tpn * Fp; op += nslots) {
+                int tpl = op / Fp, fp = op - tpl * Fp;
+                int tp = t0 / pt + tpl;
+                if (tp >= Tp) break;
+                size_t oi = ((((size_t)b * Tp + tp) * Fp + fp) * C4 + cg) * 4;   // channels-last index of the pooled element
+                if (MODE == 1) {
+                    f32x4 m = {0, 0, 0, 0};
+                    for (int df = 0; df < pf; ++df)
+                        for (int dt = 0; dt < pt; ++dt) {
+                            f32x4 z = c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2) * sc + sh;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], z[k]);
+                        }
+                    if (drop_p > 0.f) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) m[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+                    }
+                    *(f32x4*)(out + oi) = m;
+                } else {
+                    f32x4 g = *(const f32x4*)(dout + oi);
+                    if (drop_p > 0.f) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+                    }
+                    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, bx = {0, 0, 0, 0};
+                    int bidx[4] = {0, 0, 0, 0};
+                    int widx = 0;
+                    for (int df = 0; df < pf; ++df)
+                        for (int dt = 0; dt < pt; ++dt, ++widx) {
+                            f32x4 v = c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2);
+                            f32x4 z = v * sc + sh;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (z[k] > best[k]) { best[k] = z[k]; bx[k] = (v[k] - mu[k]) * rs[k]; bidx[k] = widx; }
+                        }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!(best[k] > 0.f)) g[k] = 0.f;
+                    if (MODE == 2) {
+                        a1 += g;
+                        a2 += g * bx;
+                    } else {
+                        widx = 0;
+                        for (int df = 0; df < pf; ++df)
+                            for (int dt = 0; dt < pt; ++dt, ++widx) {
+                                const int tl = tpl * pt + dt, f = fp * pf + df;
+                                f32x4 v = c1_conv<CIN>(W, halo, tl, f, F2);
+                                f32x4 o;
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float xh = (v[k] - mu[k]) * rs[k];
+                                    float gk = (bidx[k] == widx) ? g[k] : 0.f;
+                                    o[k] = sc[k] * (gk - sg[k] - xh * sgx[k]);
+                                }
+                                a1 += o;
+#pragma unroll
+                                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                                    for (int kw = 0; kw < 3; ++kw) {
+                                        const float* hp = halo + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+                                        for (int ci = 0; ci < CIN; ++ci) dw[(kh * 3 + kw) * CIN + ci] += hp[ci] * o;
+                                    }
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) return;
+    // block reduction in fixed slot order
+    __syncthreads();
+    float* red = smem;                                        // [nslots][NV][C], NV = 2 (stats / reduce) or 1 + 9*CIN
+    constexpr int NV = (MODE == 3) ? 1 + 9 * CIN : 2;
+    if (active) {
+        *(f32x4*)(red + (slot * NV + 0) * C + cg * 4) = a1;
+        if (MODE != 3) *(f32x4*)(red + (slot * NV + 1) * C + cg * 4) = a2;
+        else {
+#pragma unroll
+            for (int k = 0; k < 9 * CIN; ++k) *(f32x4*)(red + (slot * NV + 1 + k) * C + cg * 4) = dw[k];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NV * C; i += 256) {
+        int which = i / C, c = i - which * C;
+        float a = 0.f;
+        for (int s = 0; s < nslots; ++s) a += red[(s * NV + which) * C + c];
+        partials[(size_t)blockIdx.x * NV * C + i] = a;
+    }
+}
+
+// dW[co][ci][tap] = sum_r part[r][1 + tap*Cin + ci][co]   (row 0 of each block is the bias gradient)
+__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_k(const float* __restrict__ part, int rows, int Cin, int C,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double s1[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int NV = 1 + 9 * Cin, n = NV * C;
+    const int i = blockIdx.x * 32 + cl;
+    double a = 0.0;
+    if (i < n)
+        for (int r = sl; r < rows; r += 32) a += (double)part[(size_t)r * n + i];
+    s1[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        double A = 0.0;
+        for (int s = 0; s < 32; ++s) A += s1[s][cl];
+        int which = i / C, co = i - which * C;
+        if (which == 0) db[co] = (float)A;
+        else {
+            int tc = which - 1, tap = tc / Cin, ci = tc - tap * Cin;
+            dw[((size_t)co * Cin + ci) * 9 + tap] = (float)A;
+        }
+    }
+}
+
+static size_t c1_lds(int Cin, int F, int C, int mode) {
+    size_t halo = (size_t)(C1_TT + 2) * (F + 2) * Cin * sizeof(float);
+    size_t nv = mode == 3 ? 1 + 9 * Cin : 2;
+    size_t red = (size_t)256 * 4 * nv * sizeof(float);        // nslots*NV*C = 256*4*NV
+    return halo > red ? halo : red;
+}
+
+extern "C" int sed_conv1_fused_supported(int Cin, int F, int T, int C, int pool_f, int pool_t) {
+    if (Cin < 1 || Cin > 2 || C % 4 != 0 || C / 4 > 256 || (256 % (C / 4)) != 0) return 0;
+    if (pool_t < 1 || pool_f < 1 || C1_TT % pool_t != 0 || T % C1_TT != 0 || F % pool_f != 0 || T % pool_t != 0) return 0;
+    if (c1_lds(Cin, F, C, 3) > 150 * 1024) return 0;
+    return 1;
+}
+
+extern "C" int sed_conv1_fused_rows(int B, int T) {
+    long n = (long)B * ((T + C1_TT - 1) / C1_TT);
+    return (int)(n < C1_MAXBLOCKS ? n : C1_MAXBLOCKS);
+}
+
+template <int MODE>
+static int c1_launch(const float* x, const float* wp, const float* bias, const float* scale, const float* shift,
+                     const float* mean, const float* rstd, const float* sum_g, const float* sum_gx, const float* dout,
+                     float* out, float* partials, int B, int Cin, int F, int T, int C, int pf, int pt, float drop_p,
+                     uint64_t seed, hipStream_t s) {
+    size_t lds = c1_lds(Cin, F, C, MODE);
+    int grid = sed_conv1_fused_rows(B, T);
+    if (Cin == 1) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv1_fused_k<1, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv1_fused_k<2, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed);
+    }
+    return 0;
+}
+
+#define C1_CHECK(who)                                                                                             \
+    SED_REQUIRE(sed_conv1_fused_supported(Cin, F, T, C, pf, pt), who ": shape Cin=%d F=%d T=%d C=%d pool=(%d,%d) is not " \
+                "supported by the fused first block", Cin, F, T, C, pf, pt)
+
+extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials, int B, int Cin,
+                               int F, int T, int C, void* stream) {
+    SED_REQUIRE(x && wp && stat_partials, "conv1_stats: null pointer");
+    const int pf = 1, pt = 1;
+    C1_CHECK("conv1_stats");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_SMALL_FWD, s, 4.0 * B * Cin * (double)F * T);
+    c1_launch<0>(x, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partials, B, Cin, F, T, C, 1, 1, 0.f, 0, s);
+    SED_LAUNCH_CHECK("conv1_stats");
+    return 0;
+}
+
+extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
+                                               const float* shift, float* out, int B, int Cin, int F, int T, int C,
+                                               int pf, int pt, float drop_p, uint64_t seed, void* stream) {
+    SED_REQUIRE(x && wp && scale && shift && out, "conv1_fwd: null pointer");
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_fwd: drop_p=%f out of [0,1)", drop_p);
+    C1_CHECK("conv1_fwd");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_BN_FWD, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
+    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    SED_LAUNCH_CHECK("conv1_fwd");
+    return 0;
+}
+
+extern "C" int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
+                                    const float* scale, const float* shift, const float* mean, const float* rstd,
+                                    float* partials, int B, int Cin, int F, int T, int C, int pf, int pt, float drop_p,
+                                    uint64_t seed, void* stream) {
+    SED_REQUIRE(x && wp && dout && scale && shift && mean && rstd && partials, "conv1_bwd_reduce: null pointer");
+    C1_CHECK("conv1_bwd_reduce");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_BN_BWD_REDUCE, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
+    c1_launch<2>(x, wp, bias, scale, shift, mean, rstd, nullptr, nullptr, dout, nullptr, partials, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    SED_LAUNCH_CHECK("conv1_bwd_reduce");
+    return 0;
+}
+
+extern "C" size_t sed_conv1_bwd_apply_workspace_bytes(int B, int Cin, int T, int C) {
+    return (size_t)sed_conv1_fused_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
+}
+
+extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias, const float* dout,
+                                         const float* scale, const float* shift, const float* mean, const float* rstd,
+                                         const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
+                                         void* workspace, int B, int Cin, int F, int T, int C, int pf, int pt,
+                                         float drop_p, uint64_t seed, void* stream) {
+    SED_REQUIRE(x && wp && dout && scale && shift && mean && rstd && sum_g && sum_gx && dw_oihw && dbias && workspace,
+                "conv1_bwd_apply_wgrad: null pointer");
+    C1_CHECK("conv1_bwd_apply_wgrad");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_BN_BWD_APPLY, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
+    c1_launch<3>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, nullptr, (float*)workspace, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    SED_LAUNCH_CHECK("conv1_bwd_apply_wgrad");
+    int rows = sed_conv1_fused_rows(B, T), n = (1 + 9 * Cin) * C;
+    conv1_wgrad_reduce_k<<<cdiv(n, 32), 1024, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias);
+    SED_LAUNCH_CHECK("conv1_wgrad_reduce");
+    return 0;
+}

@@ -57,9 +57,13 @@ __device__ __forceinline__ void gm_store(const f32x4* reg, float* S, int tid) {
 template <int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_k(
     const float* __restrict__ A, long a_si, long a_sk, const float* __restrict__ Bm, long b_sk, long b_sj,
-    float* __restrict__ C, long ldc, const float* __restrict__ bias, float beta, int M, int N, int K,
-    int a_vec, int b_vec) {
+    float* __restrict__ C, long ldc, const float* __restrict__ bias, float beta, int M, int N, int Kfull,
+    int a_vec, int b_vec, int k_len, long slab_stride) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
+    // split-K: blockIdx.z owns k in [kb, K) and writes its partial product to slab z of C
+    const int kb = blockIdx.z * k_len;
+    const int K = (kb + k_len < Kfull) ? kb + k_len : Kfull;
+    C += (long)blockIdx.z * slab_stride;
     constexpr int A_FLOATS = A_KC ? BM * GM_LDK : GM_BK * BM;
     constexpr int B_FLOATS = B_KC ? BN * GM_LDK : GM_BK * BN;
     constexpr int NA = 2 * WM, NB = 2 * WN;           // float4 per thread per K-step
@@ -81,13 +85,13 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
             for (int j = 0; j < 16; ++j) acc[t][u][j] = 0.f;
 
     f32x4 ra[NA], rb[NB];
-    gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, 0, tid);
-    gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, 0, tid);
+    gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, kb, tid);
+    gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, kb, tid);
     gm_store<A_KC, NA, BM>(ra, As0, tid);
     gm_store<B_KC, NB, BN>(rb, Bs0, tid);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < K; k0 += GM_BK) {
+    for (int k0 = kb; k0 < K; k0 += GM_BK) {
         const bool more = k0 + GM_BK < K;
         if (more) {
             gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, k0 + GM_BK, tid);
@@ -150,30 +154,59 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
 
 template <int WM, int WN, bool AKC, bool BKC>
 static int launch_gemm2(dim3 grid, hipStream_t s, const float* A, long a_si, long a_sk, const float* B, long b_sk,
-                        long b_sj, float* C, long ldc, const float* bias, float beta, int M, int N, int K, int av, int bv) {
+                        long b_sj, float* C, long ldc, const float* bias, float beta, int M, int N, int K, int av, int bv,
+                        int k_len, long slab) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr size_t lds = 2 * ((AKC ? BM * GM_LDK : GM_BK * BM) + (BKC ? BN * GM_LDK : GM_BK * BN)) * sizeof(float);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_k<WM, WN, AKC, BKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error("gemm_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     }
-    gemm_f32_k<WM, WN, AKC, BKC><<<grid, 256, lds, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    gemm_f32_k<WM, WN, AKC, BKC><<<grid, 256, lds, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
     return 0;
 }
 
 template <int WM, int WN>
 static int launch_gemm(bool akc, bool bkc, hipStream_t s, const float* A, long a_si, long a_sk,
                        const float* B, long b_sk, long b_sj, float* C, long ldc, const float* bias, float beta,
-                       int M, int N, int K, int av, int bv) {
-    dim3 grid(cdiv(N, 64 * WN), cdiv(M, 64 * WM));
-    if (akc && bkc) return launch_gemm2<WM, WN, true, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    if (akc && !bkc) return launch_gemm2<WM, WN, true, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    if (!akc && bkc) return launch_gemm2<WM, WN, false, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    return launch_gemm2<WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+                       int M, int N, int K, int av, int bv, int splits = 1, int k_len = 0, long slab = 0) {
+    dim3 grid(cdiv(N, 64 * WN), cdiv(M, 64 * WM), splits);
+    if (k_len == 0) k_len = K;
+    if (akc && bkc) return launch_gemm2<WM, WN, true, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    if (akc && !bkc) return launch_gemm2<WM, WN, true, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    if (!akc && bkc) return launch_gemm2<WM, WN, false, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    return launch_gemm2<WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
 }
 
-extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
-                            long ldc, const float* bias, float beta, int M, int N, int K, void* stream) {
+// C[i][j] = sum_z slab[z][i][j] in slab order
+__global__ void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits, int M, int N, float* __restrict__ C, long ldc) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n = (long)M * N;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int z = 0; z < splits; ++z) a += slabs[(size_t)z * n + i];
+    C[(i / N) * ldc + (i % N)] = a;
+}
+
+// Split-K plan for small-output / long-K products (the GRU weight gradients dW_hh, dW_ih of upper layers):
+// enough K-slices to give every CU a 64x64 tile; 1 = do not split.
+static int gemm_splits(int M, int N, int K) {
+    long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
+    if (blocks >= 96 || K < 1024) return 1;
+    int s = (int)(256 / blocks);
+    int maxs = K / 128;
+    if (s > maxs) s = maxs;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : s;
+}
+
+extern "C" size_t sed_gemm_f32_workspace_bytes(int M, int N, int K) {
+    int s = gemm_splits(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
+                     long ldc, const float* bias, float beta, int M, int N, int K, void* workspace, void* stream) {
     SED_REQUIRE(A && B && C, "gemm_f32: null pointer");
     SED_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_f32: bad sizes M=%d N=%d K=%d ldc=%ld", M, N, K, ldc);
     SED_REQUIRE(a_si == 1 || a_sk == 1, "gemm_f32: A must be contiguous along i or k (strides %ld,%ld)", a_si, a_sk);
@@ -184,6 +217,18 @@ extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B
     int bv = (((uintptr_t)B & 15) == 0) && ((bkc ? b_sj : b_sk) % 4 == 0);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_GEMM, s, 2.0 * M * (double)N * K);
+    const int splits = workspace ? gemm_splits(M, N, K) : 1;
+    if (splits > 1) {
+        SED_REQUIRE(!bias && beta == 0.f, "gemm_f32: split-K path takes no bias / beta");
+        int k_len = ((cdiv(K, splits) + GM_BK - 1) / GM_BK) * GM_BK;
+        int rc = launch_gemm<1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, (float*)workspace, N, nullptr, 0.f, M, N, K, av, bv,
+                                   cdiv(K, k_len), k_len, (long)M * N);
+        if (rc) return rc;
+        SED_LAUNCH_CHECK("gemm_f32 (split-K)");
+        gemm_splitk_reduce_k<<<cdiv((long)M * N, 256), 256, 0, s>>>((const float*)workspace, cdiv(K, k_len), M, N, C, ldc);
+        SED_LAUNCH_CHECK("gemm_splitk_reduce");
+        return 0;
+    }
     // largest tile that still gives the 256 CUs enough workgroups
     const long fill = 160;
     long b22 = (long)cdiv(M, 128) * cdiv(N, 128), b21 = (long)cdiv(M, 128) * cdiv(N, 64), b12 = (long)cdiv(M, 64) * cdiv(N, 128);
@@ -195,6 +240,16 @@ extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B
     if (rc) return rc;
     SED_LAUNCH_CHECK("gemm_f32");
     return 0;
+}
+
+extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
+                            long ldc, const float* bias, float beta, int M, int N, int K, void* stream) {
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, nullptr, stream);
+}
+
+extern "C" int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
+                               long ldc, int M, int N, int K, void* workspace, void* stream) {
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, nullptr, 0.f, M, N, K, workspace, stream);
 }
 
 // ───────────────────────── small dense head ─────────────────────────

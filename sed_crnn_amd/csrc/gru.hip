@@ -12,7 +12,8 @@
 //                                   h' = (1-z)*n + z*h,  h0 = 0.
 #include "common.h"
 
-#define GRU_BT 4   // batch rows per workgroup
+// batch rows per workgroup: 4, or 2 for H >= 128 (register budget of the backward kernel; twice the workgroups)
+static inline int gru_bt(int H) { return H >= 128 ? 2 : 4; }
 
 __global__ void gru_pack_whh_t_k(const float* __restrict__ w0, const float* __restrict__ w1,
                                  float* __restrict__ wt, int H) {
@@ -28,7 +29,7 @@ __global__ void gru_pack_whh_t_k(const float* __restrict__ w0, const float* __re
 
 constexpr int gru_nt(int hreg) { return hreg > 0 ? ((3 * hreg + 63) / 64) * 64 : 1024; }
 
-template <int HREG>
+template <int HREG, int GRU_BT>
 __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
     const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
     const float* __restrict__ bhh1, float* __restrict__ out, float* __restrict__ saved, int B, int T, int H) {
@@ -52,20 +53,23 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
     for (int i = g; i < GRU_BT * H; i += blockDim.x) h_s[i] = 0.f;
     __syncthreads();
 
+    // input projections of a step are fetched one step ahead (an HBM miss is ~1 us: longer than a whole step)
+    float gr[GRU_BT], gz[GRU_BT], gn[GRU_BT], nr[GRU_BT], nz[GRU_BT], nn[GRU_BT];
+    auto fetch_gi = [&](int s, float* a, float* bq, float* c) {
+        const int tt = dir ? (T - 1 - s) : s;
+#pragma unroll
+        for (int b = 0; b < GRU_BT; ++b) {
+            int bg = b0 + b;
+            if (gate && bg < B && s < T) {
+                const float* p = gi + (((size_t)bg * T + tt) * 2 + dir) * H3;
+                a[b] = p[g]; bq[b] = p[H + g]; c[b] = p[2 * H + g];
+            } else { a[b] = bq[b] = c[b] = 0.f; }
+        }
+    };
+    fetch_gi(0, gr, gz, gn);
     for (int s = 0; s < T; ++s) {
         const int tt = dir ? (T - 1 - s) : s;
-        // prefetch this step's input projections (gate threads) so the latency hides under the matvec
-        float gr[GRU_BT], gz[GRU_BT], gn[GRU_BT];
-        if (gate) {
-#pragma unroll
-            for (int b = 0; b < GRU_BT; ++b) {
-                int bg = b0 + b;
-                if (bg < B) {
-                    const float* p = gi + (((size_t)bg * T + tt) * 2 + dir) * H3;
-                    gr[b] = p[g]; gz[b] = p[H + g]; gn[b] = p[2 * H + g];
-                } else { gr[b] = gz[b] = gn[b] = 0.f; }
-            }
-        }
+        fetch_gi(s + 1, nr, nz, nn);
         if (row) {
             float acc[GRU_BT];
 #pragma unroll
@@ -114,11 +118,13 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
                 }
             }
         }
+#pragma unroll
+        for (int b = 0; b < GRU_BT; ++b) { gr[b] = nr[b]; gz[b] = nz[b]; gn[b] = nn[b]; }
         __syncthreads();
     }
 }
 
-template <int HREG>
+template <int HREG, int GRU_BT>
 __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ whh0,
     const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bpart,
@@ -146,17 +152,31 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;   // bias-gradient partial sums over this block's rows and steps
     __syncthreads();
 
+    float cs[GRU_BT][6], ns[GRU_BT][6];          // r, z, n, gh_n, h_prev, dout of the current / next step
+    auto fetch_sv = [&](int s, float (*q)[6]) {
+        const int tt = dir ? s : (T - 1 - s);
+#pragma unroll
+        for (int b = 0; b < GRU_BT; ++b) {
+            int bg = b0 + b;
+            if (gate && bg < B && s < T) {
+                const float* sp = saved + ((((size_t)bg * T + tt) * 2 + dir) * 5) * H + g;
+                q[b][0] = sp[0]; q[b][1] = sp[H]; q[b][2] = sp[2 * H]; q[b][3] = sp[3 * H]; q[b][4] = sp[4 * H];
+                q[b][5] = dout[((size_t)bg * T + tt) * 2 * H + dir * H + g];
+            }
+        }
+    };
+    fetch_sv(0, cs);
     for (int s = 0; s < T; ++s) {
         const int tt = dir ? s : (T - 1 - s);    // reverse of the forward processing order
+        fetch_sv(s + 1, ns);
         if (gate) {
 #pragma unroll
             for (int b = 0; b < GRU_BT; ++b) {
                 int bg = b0 + b;
                 float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dghn = 0.f, carry = 0.f;
                 if (bg < B) {
-                    const float* sp = saved + ((((size_t)bg * T + tt) * 2 + dir) * 5) * H + g;
-                    float r = sp[0], z = sp[H], n = sp[2 * H], ghn = sp[3 * H], hp = sp[4 * H];
-                    float dh = dout[((size_t)bg * T + tt) * 2 * H + dir * H + g] + dhc[b] +
+                    float r = cs[b][0], z = cs[b][1], n = cs[b][2], ghn = cs[b][3], hp = cs[b][4];
+                    float dh = cs[b][5] + dhc[b] +
                                part_s[(0 * GRU_BT + b) * H + g] + part_s[(1 * GRU_BT + b) * H + g] +
                                part_s[(2 * GRU_BT + b) * H + g];
                     float dn = dh * (1.f - z);
@@ -204,6 +224,10 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
 #pragma unroll
             for (int b = 0; b < GRU_BT; ++b) part_s[(p * GRU_BT + b) * H + k] = acc[b];
         }
+#pragma unroll
+        for (int b = 0; b < GRU_BT; ++b)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) cs[b][e] = ns[b][e];
         __syncthreads();
     }
     if (bpart && gate) {
@@ -233,12 +257,15 @@ extern "C" size_t sed_gru_seq_workspace_bytes(int H) { return (size_t)2 * 3 * H 
 
 #define GRU_DISPATCH(KERNEL, ...)                                                             \
     switch (H) {                                                                              \
-        case 8: KERNEL<8><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                          \
-        case 16: KERNEL<16><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
-        case 32: KERNEL<32><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
-        case 64: KERNEL<64><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                        \
-        case 128: KERNEL<128><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                      \
-        default: KERNEL<0><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                         \
+        case 8: KERNEL<8, 4><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                       \
+        case 16: KERNEL<16, 4><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                     \
+        case 32: KERNEL<32, 4><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                     \
+        case 64: KERNEL<64, 4><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                     \
+        case 128: KERNEL<128, 2><<<grid, nt, lds, s>>>(__VA_ARGS__); break;                   \
+        default:                                                                              \
+            if (bt == 2) KERNEL<0, 2><<<grid, nt, lds, s>>>(__VA_ARGS__);                     \
+            else KERNEL<0, 4><<<grid, nt, lds, s>>>(__VA_ARGS__);                             \
+            break;                                                                            \
     }
 
 extern "C" int sed_gru_seq_fwd(const float* gi, const float* const* whh, const float* const* bhh, float* out,
@@ -250,16 +277,17 @@ extern "C" int sed_gru_seq_fwd(const float* gi, const float* const* whh, const f
     int n = 2 * 3 * H * H;
     gru_pack_whh_t_k<<<cdiv(n, 256), 256, 0, s>>>(whh[0], whh[1], wt, H);
     SED_LAUNCH_CHECK("gru_pack_whh_t");
-    dim3 grid(cdiv(B, GRU_BT), 2);
+    const int bt = gru_bt(H);
+    dim3 grid(cdiv(B, bt), 2);
     int nt = gru_threads(H);
-    size_t lds = (size_t)GRU_BT * 4 * H * sizeof(float);
+    size_t lds = (size_t)bt * 4 * H * sizeof(float);
     SedProfScope prof(SED_K_GRU_FWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
     GRU_DISPATCH(gru_seq_fwd_k, gi, wt, bhh[0], bhh[1], out, saved, B, T, H);
     SED_LAUNCH_CHECK("gru_seq_fwd");
     return 0;
 }
 
-extern "C" size_t sed_gru_seq_bwd_workspace_bytes(int B, int H) { return (size_t)cdiv(B, GRU_BT) * 2 * 4 * H * sizeof(float); }
+extern "C" size_t sed_gru_seq_bwd_workspace_bytes(int B, int H) { return (size_t)cdiv(B, gru_bt(H)) * 2 * 4 * H * sizeof(float); }
 
 extern "C" int sed_gru_seq_bwd(const float* dout, const float* saved, const float* const* whh, float* dgi,
                                float* dgh, float* const* dbih, float* const* dbhh, void* workspace, int B, int T,
@@ -270,14 +298,15 @@ extern "C" int sed_gru_seq_bwd(const float* dout, const float* saved, const floa
     float* bpart = want_bias ? (float*)workspace : nullptr;
     SED_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && 3 * H <= 1024, "gru_seq_bwd: H=%d must be a multiple of 4 and <= 341", H);
     hipStream_t s = as_stream(stream);
-    dim3 grid(cdiv(B, GRU_BT), 2);
+    const int bt = gru_bt(H);
+    dim3 grid(cdiv(B, bt), 2);
     int nt = gru_threads(H);
-    size_t lds = (size_t)GRU_BT * 6 * H * sizeof(float);
+    size_t lds = (size_t)bt * 6 * H * sizeof(float);
     SedProfScope prof(SED_K_GRU_BWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
     GRU_DISPATCH(gru_seq_bwd_k, dout, saved, whh[0], whh[1], dgi, dgh, bpart, B, T, H);
     SED_LAUNCH_CHECK("gru_seq_bwd");
     if (want_bias) {
-        gru_bias_grad_k<<<cdiv(8 * H, 256), 256, 0, s>>>(bpart, cdiv(B, GRU_BT), H, dbih[0], dbih[1], dbhh[0], dbhh[1]);
+        gru_bias_grad_k<<<cdiv(8 * H, 256), 256, 0, s>>>(bpart, cdiv(B, bt), H, dbih[0], dbih[1], dbhh[0], dbhh[1]);
         SED_LAUNCH_CHECK("gru_bias_grad");
     }
     return 0;

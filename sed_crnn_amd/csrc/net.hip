@@ -9,7 +9,7 @@
 
 namespace {
 
-struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw; float drop; };
+struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop; };
 struct GruL { int in, H; };
 
 struct Layout {
@@ -25,7 +25,7 @@ struct Layout {
     size_t act[SED_MAX_DENSE];
     // backward only
     size_t bn_part, sum_g, sum_gx, dbias_part, dconv, gradA, wgrad_ws, dgi, dgh, gru_bws, dgout[SED_MAX_GRU];
-    size_t dact[SED_MAX_DENSE], lin_ws;
+    size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws;
     size_t total;     // floats
 };
 
@@ -55,10 +55,16 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
                     "net: block %d: T=%d/F=%d not divisible by pool (%d,%d)", l, T, F, q.pt, q.pf);
         SED_REQUIRE(q.drop >= 0.f && q.drop < 1.f, "net: drop_p[%d]=%f out of [0,1)", l, q.drop);
         q.Tp = T / q.pt; q.Fp = F / q.pf;
-        q.rows = sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
-        SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
-        q.bn_rows = sed_bn_bwd_rows(c->B, q.T, q.pt);
-        size_t nout = (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
+        // block 1 with <= 2 input channels: the conv output is recomputed in every pass and never stored (conv1.hip)
+        q.fused = (l == 0 && c->n_conv > 1 && sed_conv1_fused_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt)) ? 1 : 0;
+        if (q.fused) {
+            q.rows = q.bn_rows = sed_conv1_fused_rows(c->B, q.T);
+        } else {
+            q.rows = sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
+            SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
+            q.bn_rows = sed_bn_bwd_rows(c->B, q.T, q.pt);
+        }
+        size_t nout = q.fused ? 64 : (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
         L->wp_f[l] = cv.take((size_t)9 * q.C * q.Cin);
         L->wp_d[l] = cv.take((size_t)9 * q.C * q.Cin);
         L->conv_out[l] = cv.take(nout);
@@ -67,7 +73,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->pooled[l] = cv.take(npool);
         if (nout > max_conv) max_conv = nout;
         if (npool > max_pool) max_pool = npool;
-        size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
+        size_t wg = (q.fused ? sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C)
+                             : sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C)) / sizeof(float);
         if (wg > max_wgrad) max_wgrad = wg;
         if (q.bn_rows > max_bn_rows) max_bn_rows = q.bn_rows;
         if (q.C > maxC) maxC = q.C;
@@ -111,6 +118,14 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         for (int i = 0; i < c->n_gru; ++i) L->dgout[i] = cv.take(M * 2 * c->H[i]);
         for (int j = 0; j < c->n_dense - 1; ++j) L->dact[j] = cv.take(M * c->D[j]);
         L->lin_ws = cv.take(max_lin_ws);
+        size_t gw = 0;
+        for (int i = 0; i < c->n_gru; ++i) {
+            size_t a = sed_gemm_f32_workspace_bytes(3 * c->H[i], c->H[i], L->M) / sizeof(float);
+            size_t b = sed_gemm_f32_workspace_bytes(6 * c->H[i], L->gr[i].in, L->M) / sizeof(float);
+            if (a > gw) gw = a;
+            if (b > gw) gw = b;
+        }
+        L->gemm_ws = cv.take(gw + 64);
     }
     L->total = cv.off;
     return 0;
@@ -148,8 +163,12 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
                     "net_forward: missing parameters of conv block %d", l);
         SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
                                          q.C, q.Cin, stream));
-        SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
-                                training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+        if (q.fused) {
+            if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], B, q.Cin, q.F, q.T, q.C, stream));
+        } else {
+            SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
+                                    training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+        }
         if (training)
             SED_TRY(sed_bn_finalize_train(ws + L.stat[l], q.rows, q.C, (double)B * q.T * q.F, p->bn_g[l], p->bn_b[l],
                                           p->bn_rm[l], p->bn_rv[l], c->bn_momentum, c->bn_eps, ws + L.mean[l],
@@ -158,9 +177,14 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
             SED_TRY(sed_bn_finalize_eval(p->bn_g[l], p->bn_b[l], p->bn_rm[l], p->bn_rv[l], c->bn_eps, q.C,
                                          ws + L.scale[l], ws + L.shift[l], stream));
         const int last = (l == L.n_conv - 1);
-        SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
-                                          q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
-                                          layer_seed(seed, l), stream));
+        if (q.fused)
+            SED_TRY(sed_conv1_bn_relu_pool_drop_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.scale[l], ws + L.shift[l],
+                                                    ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
+                                                    training ? q.drop : 0.f, layer_seed(seed, l), stream));
+        else
+            SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
+                                              q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
+                                              layer_seed(seed, l), stream));
         in = ws + L.pooled[l];
     }
     const int M = L.M;
@@ -234,12 +258,12 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             float* dbhh[2] = {g->gru_bhh[i][0], g->gru_bhh[i][1]};
             SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, dbih, dbhh, ws + L.gru_bws, B, L.Tp, H, stream));
             for (int d = 0; d < 2; ++d)      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
-                SED_TRY(sed_gemm_f32(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
-                                     g->gru_whh[i][d], H, nullptr, 0.f, 3 * H, H, M, stream));
+                SED_TRY(sed_gemm_f32_ws(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
+                                        g->gru_whh[i][d], H, 3 * H, H, M, ws + L.gemm_ws, stream));
             const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
                                g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
             if (fused) {                     // both directions at once: dW_ih = dgi^T x (M = 6H), dx = dgi W_ih (K = 6H)
-                SED_TRY(sed_gemm_f32(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, nullptr, 0.f, 6 * H, K, M, stream));
+                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
                 SED_TRY(sed_gemm_f32(dgi, 6 * H, 1, p->gru_wih[i][0], K, 1, dxin, K, nullptr, 0.f, M, K, 6 * H, stream));
             } else {
                 for (int d = 0; d < 2; ++d) {
@@ -258,6 +282,16 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         const float drop = q.drop;
         const uint64_t sd = layer_seed(seed, l);
         SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
+        if (q.fused) {
+            SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                         ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
+                                         drop, sd, stream));
+            SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], stream));
+            SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                              ws + L.mean[l], ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, g->conv_w[l],
+                                              g->conv_b[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, drop, sd, stream));
+            continue;
+        }
         const float* y = ws + L.conv_out[l];
         SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
                                                  ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last,

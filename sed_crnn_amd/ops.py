@@ -114,6 +114,19 @@ def gemm(A, B, bias=None, out=None, beta=0.0):
     return out
 
 
+def gemm_ws(A, B, out=None):
+    """out = A @ B through the split-K capable entry (workspace allocated here)."""
+    M, K = A.shape
+    _, N = B.shape
+    if out is None:
+        out = torch.empty(M, N, device=A.device)
+    nb = lib().sed_gemm_f32_workspace_bytes(M, N, K)
+    ws = torch.empty(nb // 4 + 1, device=A.device) if nb else None
+    check(lib().sed_gemm_f32_ws(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
+                                out.stride(0), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_ws")
+    return out
+
+
 def linear_fwd(x, W, b, relu=False):
     M, K = x.shape
     N = W.shape[0]
@@ -196,3 +209,34 @@ def grad_norm_clip_coef(g, max_norm):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
     check(lib().sed_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                               ptr(grad_scale), stream_ptr()), "adam_step")
+
+
+def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p=0.0, seed=0, eps=1e-5):
+    """First conv block through the recompute-fused entries (train statistics).
+    x [B,Cin,F,T] -> pooled [B,T/pt,F/pf,C]; with dout also (dw, dbias, dgamma, dbeta)."""
+    B, Cin, F, T = x.shape
+    Cc = w.shape[0]
+    L = lib()
+    assert L.sed_conv1_fused_supported(Cin, F, T, Cc, pool_f, pool_t)
+    wf, _ = conv3x3_pack(w)
+    rows = L.sed_conv1_fused_rows(B, T)
+    stat = torch.empty(rows, 2, Cc, device=x.device)
+    check(L.sed_conv1_stats(ptr(_f32c(x)), ptr(wf), ptr(bias), ptr(stat), B, Cin, F, T, Cc, stream_ptr()), "conv1_stats")
+    rm, rv = torch.zeros(Cc, device=x.device), torch.ones(Cc, device=x.device)
+    mean, rstd, scale, shift = bn_finalize_train(stat, B * T * F, gamma, beta, rm, rv, eps=eps)
+    out = torch.empty(B, T // pool_t, F // pool_f, Cc, device=x.device)
+    check(L.sed_conv1_bn_relu_pool_drop_fwd(ptr(x), ptr(wf), ptr(bias), ptr(scale), ptr(shift), ptr(out), B, Cin, F, T, Cc,
+                                            pool_f, pool_t, drop_p, seed, stream_ptr()), "conv1_fwd")
+    if dout is None:
+        return out
+    part = torch.empty(rows, 2, Cc, device=x.device)
+    check(L.sed_conv1_bwd_reduce(ptr(x), ptr(wf), ptr(bias), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                                 ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, stream_ptr()), "conv1_bwd_reduce")
+    sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=x.device) for _ in range(4))
+    check(L.sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta), stream_ptr()), "bn_bwd_finalize")
+    ws = torch.empty(L.sed_conv1_bwd_apply_workspace_bytes(B, Cin, T, Cc) // 4 + 1, device=x.device)
+    dw, db = torch.empty_like(w), torch.empty(Cc, device=x.device)
+    check(L.sed_conv1_bwd_apply_wgrad(ptr(x), ptr(wf), ptr(bias), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                                      ptr(sum_g), ptr(sum_gx), ptr(dw), ptr(db), ptr(ws), B, Cin, F, T, Cc, pool_f, pool_t,
+                                      drop_p, seed, stream_ptr()), "conv1_bwd_apply_wgrad")
+    return out, dw, db, dgamma, dbeta

@@ -103,6 +103,28 @@ def test_bn_relu_pool_fwd_bwd(ops, B, T, Fm, Cc, pf, pt, tcf):
     assert float(dbias.abs().max()) < 1e-3                            # sum of BN input grads is 0 up to rounding
 
 
+@pytest.mark.parametrize("B,Cin,Fm,T,Cc,pf,pt", [(2, 1, 40, 16, 8, 1, 2), (3, 1, 40, 8, 128, 1, 2), (2, 2, 40, 8, 128, 1, 2),
+                                                 (2, 2, 40, 8, 32, 5, 1), (2, 1, 8, 12, 16, 2, 2), (1, 1, 40, 4, 64, 1, 1)])
+def test_conv1_fused_block_vs_torch(ops, B, Cin, Fm, T, Cc, pf, pt):
+    """first block with the conv recomputed in every pass: same results as conv -> BN(train) -> ReLU -> pool in torch"""
+    gen = torch.Generator().manual_seed(B + Cin * 10 + Cc)
+    x = torch.randn(B, Cin, Fm, T, generator=gen)
+    w = (torch.randn(Cc, Cin, 3, 3, generator=gen) / np.sqrt(9 * Cin)).requires_grad_(True)
+    bias = torch.randn(Cc, generator=gen).requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    beta = (torch.randn(Cc, generator=gen) * 0.2).requires_grad_(True)
+    ref = _bn_block_ref(F.conv2d(x, w, bias, padding=1), gamma, beta, pf, pt)       # [B,C,F',T']
+    dout = torch.randn(ref.shape, generator=gen)
+    ref.backward(dout)
+    out, dw, db, dgamma, dbeta = ops.conv1_fused_block(g(x), g(w.detach()), g(bias.detach()), g(gamma.detach()),
+                                                       g(beta.detach()), pf, pt, dout=g(dout.permute(0, 3, 2, 1)))
+    close(out, ref.detach().permute(0, 3, 2, 1), atol=2e-5, rtol=1e-4)
+    close(dw, w.grad, atol=2e-4, rtol=1e-3)
+    close(dgamma, gamma.grad, atol=2e-4, rtol=1e-3)
+    close(dbeta, beta.grad, atol=2e-4, rtol=1e-3)
+    assert float(db.abs().max()) < 1e-3
+
+
 def test_bn_eval_scale_shift(ops):
     Cc = 16
     gen = torch.Generator().manual_seed(5)
@@ -163,6 +185,16 @@ def test_gemm_f32_layouts(ops, M, N, K, ta, tb):
     close(out, ref.float(), atol=tol * 4, rtol=1e-4)
     out2 = ops.gemm(Ag, Bg, out=out.clone(), beta=1.0)
     close(out2, (ref + A.double() @ Bm.double()).float(), atol=tol * 8, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(384, 128, 4096), (768, 256, 4096), (96, 32, 2048), (48, 16, 1024), (130, 70, 1500)])
+def test_gemm_split_k_is_exact_sum_and_deterministic(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M + K)
+    A, Bm = torch.randn(K, M, generator=gen), torch.randn(K, N, generator=gen)      # dW = A^T B, both row-contiguous
+    out = ops.gemm_ws(g(A).t(), g(Bm))
+    ref = (A.double().t() @ Bm.double()).float()
+    close(out, ref, atol=2e-3, rtol=1e-4)
+    assert torch.equal(out, ops.gemm_ws(g(A).t(), g(Bm)))
 
 
 def test_gemm_strided_column_block(ops):
