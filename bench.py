@@ -23,6 +23,22 @@ WORKLOAD = dict(B=128, Cin=1, F=40, T=256, C=128, H=128, gru_layers=2, dropout=0
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 
 
+DOMINANT_KERNEL = "conv3x3_mfma_fwd2_k<4, 2>"
+
+
+def pmc_traffic_bytes():
+    """HBM traffic per launch of the dominant kernel, from the committed PMC summary (collected as the
+    MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes; FETCH_SIZE counts half of a wide
+    coalesced read on gfx950, verified here on the pure-streaming bn kernel).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_fetch_write_per_kernel.json")
+    try:
+        d = json.load(open(path))
+        e = d["void " + DOMINANT_KERNEL]
+        return int((2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_B=8, steps=3):
     """The oracle's fit step (torch.nn CPU restatement of sed.py, pinned by tests/golden) on the host cores."""
     import torch
@@ -145,9 +161,11 @@ def main():
         if n.value:
             avg_ms = ms.value / n.value
             tf = units.value / (ms.value * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_mfma_fwd_k<4> (conv2/conv3 forward + their data gradients)",
+            out["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (conv2/conv3 forward + their data gradients)",
                                "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
+                               "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this "
+                                               "command (profiles/r1): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
                                "flops_per_launch_avg": units.value / n.value}
         if not args.no_cpu_baseline:

@@ -12,7 +12,6 @@
 //              channels in LDS read with conflict-free ds_read_b128, weights double-buffered.
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
-#include <stdlib.h>
 #include "common.h"
 
 #define CV_CIC 32   // input channels per LDS chunk
@@ -195,7 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
     float* halo = smem;                             // [HR][CV_LD]
     float* wbuf = smem + HR * CV_LD;                // [2][WROWS][CV_LD]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
     const int ct = wave % NCT, mp = wave / NCT;
@@ -261,8 +260,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < CV_MTW; ++i)
-                        if (mp + i * MPARTS < nMT)
+                    for (int i = 0; i < CV_MTW; ++i)      // tiles past nMT read clamped rows and are never stored
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[j], acc[i], 0, 0, 0);
             }
             if (tap < 8) {
@@ -324,15 +322,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
 template <int NCT, int MINW>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int dbg) {
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = F + 2;
     const int HR = (TT + 2) * F2;
     const int HB = HR * CV_LD;
+    const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
     const int ct = wave % NCT, mp = wave / NCT;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     for (int i = 0; i < CV_MTW; ++i) {
         int p = (mp + i * MPARTS) * 32 + r;
         if (p >= MROWS) p = MROWS - 1;
-        int tl = p / F, f = p - tl * F;
+        int tl = sed_fdiv(p, invF), f = p - tl * F;
         abase[i] = (tl * F2 + f) * CV_LD + 4 * h;
     }
     f32x16 acc[CV_MTW];
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             f32x4 v = {0, 0, 0, 0};
             if (i < HR * 8) {
                 int row = i >> 3, q = i & 7;
-                int tt = row / F2, ff = row - tt * F2;
+                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
                 int t = t0 + tt - 1, f = ff - 1;
                 if (t >= 0 && t < T && f >= 0 && f < F)
                     v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
@@ -408,8 +407,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < CV_MTW; ++i)
-                        if (mp + i * MPARTS < nMT)
+                    for (int i = 0; i < CV_MTW; ++i)      // tiles past nMT read clamped rows and are never stored
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[g][j], acc[i], 0, 0, 0);
             }
 #pragma unroll
@@ -430,17 +428,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             for (int j = 0; j < 16; ++j) {
                 int row = (j & 3) + 8 * (j >> 2) + 4 * h;
                 int p = mt * 32 + row;
-                int tl = p / F, f = p - tl * F;
+                int tl = sed_fdiv(p, invF), f = p - tl * F;
                 if (p < MROWS && t0 + tl < T) {
                     float v = acc[i][j] + bv;
-                    if (!(dbg & 1)) y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
+                    y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
                     s1 += v;
                     s2 += v * v;
                 }
             }
         }
     }
-    if (stat && !(dbg & 2)) {
+    if (stat) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         float* red = smem;                          // [4 waves][2][32]; the last loop barrier already passed
@@ -487,21 +485,16 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
         dim3 grid(p.tblocks, B, Cout / (32 * p.nct));
-        static const int variant = getenv("SED_CONV_VARIANT") ? atoi(getenv("SED_CONV_VARIANT")) : 2;   // tuning knob
-        static const int dbg = getenv("SED_CONV_DEBUG") ? atoi(getenv("SED_CONV_DEBUG")) : 0;            // timing-only ablations
-        if (p.v2 && variant >= 1) {
-            if (p.nct == 4 && variant == 1) {
-                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 1>), p.lds));
-                conv3x3_mfma_fwd2_k<4, 1><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
-            } else if (p.nct == 4) {
+        if (p.v2) {
+            if (p.nct == 4) {
                 SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+                conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
             } else if (p.nct == 2) {
                 SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+                conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
             } else {
                 SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, dbg);
+                conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
             }
         } else if (p.nct == 4) {
             p.lds = ((size_t)(p.TT + 2) * (F + 2) * CV_LD + 2 * 32 * p.nct * CV_LD) * sizeof(float);
@@ -652,7 +645,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     const int HR = (TT + 2) * F2;
     const int MROWS = TT * F;
     const int XH = HR * 32, DYS = MROWS * 128, BUF = XH + DYS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
 
@@ -671,7 +665,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
             f32x4 v = {0, 0, 0, 0};
             if (i < HR * 8) {
                 int row = i >> 3, q = i & 7;
-                int tt = row / F2, ff = row - tt * F2;
+                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
                 int t = t0 + tt - 1, f = ff - 1;
                 if (t >= 0 && t < T && f >= 0 && f < F)
                     v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
             f32x4 v = {0, 0, 0, 0};
             if (i < MROWS * 32) {
                 int row = i >> 5, q = i & 31;
-                int tl = row / F, f = row - tl * F;
+                int tl = sed_fdiv(row, invF), f = row - tl * F;
                 if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
             }
             pd[u] = v;
@@ -755,7 +749,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
             __syncthreads();
             for (int i = tid; i < HR * 8; i += 256) {
                 int row = i >> 3, q = i & 7;
-                int tt = row / F2, ff = row - tt * F2;
+                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
                 int t = t0 + tt - 1, f = ff - 1;
                 f32x4 v = {0, 0, 0, 0};
                 if (t >= 0 && t < T && f >= 0 && f < F)
@@ -764,7 +758,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
             }
             for (int i = tid; i < MROWS * 32; i += 256) {
                 int row = i >> 5, q = i & 31;
-                int tl = row / F, f = row - tl * F;
+                int tl = sed_fdiv(row, invF), f = row - tl * F;
                 f32x4 v = {0, 0, 0, 0};
                 if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
                 *(f32x4*)(smem + XH + i * 4) = v;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
     float* As0 = smem;                                // [2][A_FLOATS]
     float* Bs0 = smem + 2 * A_FLOATS;                 // [2][B_FLOATS]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;

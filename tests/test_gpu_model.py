@@ -3,6 +3,8 @@
  (b) the CPU oracle (oracle/crnn_ref.py) on identical seeded inputs / weights,
 plus size-independent properties at the BASELINE size.  Tolerance for probabilities: 1e-3 (north star);
 tighter where stated."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,6 +121,54 @@ def test_g4_lightning_net_focal(sed):
     for k, v in _sd(d, "sd1.").items():
         if v.dtype.is_floating_point:
             _cmp(sd[k], v, atol=1e-5, rtol=1e-4, msg=k)
+
+
+def test_g4_crnn_lightning_module_hooks(sed, tmp_path):
+    """CRNNLightning mirror: training_step / _aggregate / configure_optimizers against the reference module's outputs"""
+    d = load_golden("g4_lightning.npz")
+    lm = sed.CRNNLightning(fold_id=1, art_dir=str(tmp_path), dropout=0.0)
+    assert list(lm.state_dict().keys())[0] == "model.conv_stack.0.weight"
+    lm.model.load_state_dict(_sd(d))
+    lm.cuda()
+    x, y = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["y"]).cuda()
+    lm.train()
+    loss = lm.training_step((x, y), 0)
+    assert abs(loss.item() - float(d["loss_train"])) < 1e-5
+    assert lm.logged["train_loss"] is loss
+    _cmp(lm._buf["train"]["preds"][0], d["preds_train"], atol=1e-4)
+    agg = lm._aggregate("train")
+    np.testing.assert_array_equal(agg["cm"], d["agg_cm"])
+    got = np.asarray([agg["loss"], agg["f1_frame"], agg["er_frame"], agg["f1_1s"], agg["er_1s"]])
+    np.testing.assert_allclose(got, d["agg_vals"], atol=1e-5, equal_nan=True)
+    assert lm._buf["train"]["preds"] == []
+    cfg = lm.configure_optimizers()
+    g0 = cfg["optimizer"].param_groups[0]
+    assert g0["lr"] == float(d["opt_lr"]) and g0["weight_decay"] == float(d["opt_wd"])
+    assert tuple(g0["betas"]) == tuple(d["opt_betas"]) and g0["eps"] == float(d["opt_eps"])
+    sch = cfg["lr_scheduler"]["scheduler"]
+    assert sch.factor == float(d["sched_factor"]) and sch.patience == int(d["sched_patience"])
+    assert cfg["lr_scheduler"]["monitor"] == str(d["monitor"]) == "val_loss"
+
+
+def test_fit_lightning_loop_checkpoints_and_early_stop(sed, tmp_path):
+    from oracle import crnn_ref
+    torch.manual_seed(3)
+    lm = sed.CRNNLightning(fold_id=2, art_dir=str(tmp_path / "art"), dropout=0.1)
+    data = [crnn_ref.synthetic_batch(8, 1, 40, 64, 8, seed=s) for s in range(3)]
+    hist = sed.fit_lightning(lm, data, data[:1], max_epochs=3, early_stop=20, ckpt_dir=str(tmp_path / "ck"))
+    assert len(hist) == 3 and all(np.isfinite(h["val_loss"]) for h in hist)
+    assert hist[-1]["train_loss"] < hist[0]["train_loss"]
+    names = sorted(os.listdir(tmp_path / "ck"))
+    assert "last.ckpt" in names and any(n.startswith("epoch000-valer") for n in names) and len(names) == 4
+    ck = torch.load(tmp_path / "ck" / "last.ckpt", weights_only=True)
+    assert ck["epoch"] == 2 and "model.gru1.weight_ih_l0" in ck["state_dict"]
+    assert set(lm.track) >= {"loss_tr", "loss_val", "er_1s_val", "f1_fr_tr"} and len(lm.track["er_1s_val"]) == 3
+    assert os.path.exists(tmp_path / "art" / "metrics_fold2.png")
+    # early stopping: a validation ER that can never improve (no positives -> nan/inf) stops after `early_stop` epochs
+    lm2 = sed.CRNNLightning(fold_id=3, art_dir=str(tmp_path / "art2"), dropout=0.0)
+    xz = torch.randn(4, 1, 40, 64)
+    hist2 = sed.fit_lightning(lm2, [(xz, torch.zeros(4, 8, 1))], [(xz, torch.zeros(4, 8, 1))], max_epochs=10, early_stop=2)
+    assert len(hist2) <= 3
 
 
 def test_g5_full_width_k1152(sed):
