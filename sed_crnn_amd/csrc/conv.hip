@@ -526,8 +526,12 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     if (p.kind == 1) {
         p.TT = 2;
         if (p.TT > T) p.TT = T;
-        if ((p.TT * F) % 2) p.kind = 0;
         p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
+        if (p.lds > 150 * 1024) {               // wide mel axis (F = 128): one time row per tile
+            p.TT = 1;
+            p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
+        }
+        if ((p.TT * F) % 2) p.kind = 0;
         if (p.lds > 150 * 1024) p.kind = 0;
         else if (2 * p.lds <= 156 * 1024 && (p.TT + 2) * (F + 2) * 8 <= 256 * WG_NX && p.TT * F * 32 <= 256 * WG_ND) {
             p.db = 1;

@@ -219,7 +219,7 @@ def _oracle_vs_hip(sed, ref, m, x, y, loss="bce", atol=1e-3):
         _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=atol)
 
 
-@pytest.mark.parametrize("cin,mel,T,H,C", [(2, 40, 32, 128, 128), (4, 128, 16, 64, 32), (1, 40, 64, 32, 16)])
+@pytest.mark.parametrize("cin,mel,T,H,C", [(2, 40, 32, 128, 128), (4, 128, 16, 64, 32), (1, 40, 64, 32, 16), (4, 128, 16, 256, 128)])
 def test_multichannel_configs_vs_oracle(sed, cin, mel, T, H, C):
     """binaural / 4-channel / 128-mel shapes of BASELINE configs 3 and 5 at sizes the oracle runs in seconds"""
     from oracle import crnn_ref
