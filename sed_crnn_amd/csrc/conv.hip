@@ -20,6 +20,7 @@
 #define WG_NX 6      // wgrad: max float4 per thread of the halo tile   ((TT+2)*(F+2)*8 <= 256*WG_NX)
 #define WG_ND 10     // wgrad: max float4 per thread of the dY tile      (TT*F*32      <= 256*WG_ND)
 
+#define CV_TPAD 56   // fwd v2: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
 #define CV_NH 8      // fwd v2: max float4 per thread of the halo tile ((TT+2)*(F+2)*8 <= 256*CV_NH)
 
 struct ConvPlan {
@@ -47,7 +48,7 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
             p.lds = ((size_t)(TT + 2) * (F + 2) * CV_LD + 2 * 32 * nct * CV_LD) * sizeof(float);
             if ((TT + 2) * (F + 2) * 8 <= 256 * CV_NH) {
                 p.v2 = 1;
-                p.lds = (size_t)2 * (TT + 2) * (F + 2) * CV_LD * sizeof(float);
+                p.lds = (size_t)2 * (TT + 2) * ((F + 2) * CV_LD + CV_TPAD) * sizeof(float);
             }
         } else {
             return p;     // MFMA-sized channels but a mel axis wider than one block tile: unsupported
@@ -328,7 +329,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = F + 2;
     const int HR = (TT + 2) * F2;
-    const int HB = HR * CV_LD;
+    // LDS pitch of one halo time-row: F2 rows of CV_LD floats + CV_TPAD.  The pad makes the 16-B slot of flattened
+    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = F*9 mod 16),
+    // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
+    const int TP = F2 * CV_LD + CV_TPAD;
+    const int HB = (TT + 2) * TP;
     const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         int p = (mp + i * MPARTS) * 32 + r;
         if (p >= MROWS) p = MROWS - 1;
         int tl = sed_fdiv(p, invF), f = p - tl * F;
-        abase[i] = (tl * F2 + f) * CV_LD + 4 * h;
+        abase[i] = tl * TP + f * CV_LD + 4 * h;
     }
     f32x16 acc[CV_MTW];
 #pragma unroll
@@ -354,6 +359,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
     f32x4 ph[CV_NH];
+    int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+#pragma unroll
+    for (int u = 0; u < CV_NH; ++u) {
+        int i = tid + u * 256;
+        int row = i >> 3, tt = sed_fdiv(row, invF2);
+        pdst[u] = (i < HR * 8) ? tt * TP + (row - tt * F2) * CV_LD + (i & 7) * 4 : -1;
+    }
     auto fetch = [&](int cc) {
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
@@ -372,8 +384,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     auto commit = [&](float* buf) {
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
-            int i = tid + u * 256;
-            if (i < HR * 8) *(f32x4*)(buf + (i >> 3) * CV_LD + (i & 7) * 4) = ph[u];
+            if (pdst[u] >= 0) *(f32x4*)(buf + pdst[u]) = ph[u];
         }
     };
     const f32x4* wl = (const f32x4*)wq + (size_t)cot * 64 + lane;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             if (tap < 8) load_b(bn, cc, tap + 1);
             else if (more) load_b(bn, cc + 1, 0);
             const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = (kw * F2 + kh) * CV_LD;
+            const int toff = kw * TP + kh * CV_LD;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 af[CV_MTW];
