@@ -205,6 +205,21 @@ int sed_logmel(const float* pcm, long n_samples, const float* window, const floa
                const float* melfb, const float* mu, const float* inv_sigma, float* out,
                int n_fft, int hop, int n_mels, int pad_mode, void* stream);
 
+/* ───────────── GPU-resident minibatch assembly (sed.py:64-79; decorte_datamodule.py:39-49,77-111; utils.py:15-41) ─────────────
+ * mel [N][C*F] (a whole fold, device-resident; channel c = columns [c*F,(c+1)*F)), lab [N][K].
+ * starts [B] window starts (clamped to [0, N-L] like the reference's fallback); tmask/fmask [B][n_masks] SpecAugment
+ * offsets (-1 = skip; zeroes time_w frames / freq_w mel bins, all channels) or NULL with n_masks = 0.
+ * x [B][C][F][L] (the network input layout), y [B][L/pool][K] = max over each group of `pool` frames. */
+int sed_window_batch(const float* mel, const float* lab, long N, int C, int F, int K, const int* starts,
+                     const int* tmask, const int* fmask, int n_masks, int time_w, int freq_w,
+                     float* x, float* y, int B, int L, int pool, void* stream);
+/* utils.split_in_seqs + split_multi_channels in one pass: feat [N][C*F] -> out [N/S][C][F][S] (time_last=1, network
+ * input) or [N/S][C][S][F] (time_last=0, the utils.py layout); the N %% S remainder is dropped. */
+int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_last, float* out, void* stream);
+/* StandardScaler.fit (feature.py:127-128): per-column mean and population sigma (sigma 0 -> 1). */
+size_t sed_col_mean_std_workspace_bytes(int F);
+int sed_col_mean_std(const float* x, long N, int F, float* mean, float* stdv, void* workspace, void* stream);
+
 /* ───────────── whole-network plan (TimePooledCRNN.forward sed.py:105-112 / crnn_lightning.py:66-73) ───────────── */
 typedef struct sed_net_cfg {
     int B, Cin, F, T;                 /* input x [B][Cin][F][T] */

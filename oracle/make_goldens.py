@@ -49,8 +49,8 @@ def _import_reference():
     pl.LightningModule = LightningModule
     pl.LightningDataModule = LightningDataModule
     sys.modules["pytorch_lightning"] = pl
-    import sed, metrics, utils, crnn_lightning          # noqa: E401
-    return sed, metrics, utils, crnn_lightning
+    import sed, metrics, utils, crnn_lightning, decorte_datamodule          # noqa: E401
+    return sed, metrics, utils, crnn_lightning, decorte_datamodule
 
 
 def sd_np(model, prefix="sd."):
@@ -61,7 +61,7 @@ def main():
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
     os.makedirs(OUT, exist_ok=True)
-    sed, metrics, utils, cl = _import_reference()
+    sed, metrics, utils, cl, ddm = _import_reference()
     bce = torch.nn.BCEWithLogitsLoss()
 
     # ── G1/G2: small sed.py net (C=8), forward (eval + train) and BCE gradients ──
@@ -215,6 +215,35 @@ def main():
          "pos_frames": np.asarray(ds.pos_frames, np.int64),
          "pooled_60": ds._pool_labels(lab[60:124]), "len": np.int64(len(ds))}
     np.savez_compressed(os.path.join(OUT, "g7_dataset.npz"), **d)
+    # ── G8: SpecAugment (decorte_datamodule.py:39-49) under seeded np.random, augmented dataset item, utils packing ──
+    d = {}
+    rs = np.random.RandomState(5)
+    for i, seed in enumerate((3, 17, 101)):
+        xw = rs.randn(40, 64).astype(np.float32)
+        np.random.seed(seed)
+        d[f"aug_in{i}"], d[f"aug_seed{i}"] = xw, np.int64(seed)
+        d[f"aug_out{i}"] = ddm._spec_augment(xw.copy())
+    mel = rs.randn(300, 40).astype(np.float32)
+    lab2 = np.zeros((300, 1), np.float32)
+    lab2[100:104] = 1
+    ds2 = ddm.HitWindowDataset(mel, lab2, augment=False)
+    import random as _random
+    _random.seed(9)
+    xi, yi = ds2[1]                                   # odd index -> a clean negative start
+    _random.seed(9)
+    start = ds2._rand_neg()
+    d["item_mel"], d["item_lab"], d["item_start"] = mel, lab2, np.int64(start)
+    d["item_x"], d["item_y"] = xi.numpy(), yi.numpy()
+    _random.seed(11)
+    xp, yp = ds2[0]                                   # even index -> a window around a positive frame
+    _random.seed(11)
+    d["item_pos_start"] = np.int64(ds2._rand_pos())
+    d["item_pos_x"], d["item_pos_y"] = xp.numpy(), yp.numpy()
+    feat = rs.randn(70, 40 * 2)
+    seqs = utils.split_in_seqs(feat, 16)
+    d["pack_feat"], d["pack_seqs"] = feat, seqs
+    d["pack_mc"] = utils.split_multi_channels(seqs, 2)
+    np.savez_compressed(os.path.join(OUT, "g8_window_aug.npz"), **d)
     print("goldens written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))/1e3:.1f} KB")

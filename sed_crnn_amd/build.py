@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsedcrnn.so")
-SOURCES = ["api.cpp", "conv.hip", "conv1.hip", "bnpool.hip", "gemm.hip", "gru.hip", "misc.hip", "logmel.hip", "net.hip"]
+SOURCES = ["api.cpp", "conv.hip", "conv1.hip", "bnpool.hip", "gemm.hip", "gru.hip", "misc.hip", "logmel.hip", "data.hip", "net.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

@@ -1,0 +1,129 @@
+// data.hip — GPU-resident minibatch assembly: the work HitWindowDataset.__getitem__ does per
+// sample in Python workers (reference sed.py:64-79; decorte_datamodule.py:39-49,77-111), utils.split_in_seqs /
+// split_multi_channels (utils.py:15-41) and StandardScaler.fit (feature.py:127-128), as HBM-bound kernels over a
+// fold that stays resident in device memory.
+#include "common.h"
+
+// One workgroup per sample: gather L frames x (C*F) mel bins, transpose through LDS to the network input layout
+// x[b][c][f][t] (time contiguous), zero the SpecAugment masks, max-pool the labels.
+__global__ __launch_bounds__(256) void window_batch_k(
+    const float* __restrict__ mel, const float* __restrict__ lab, long N, int C, int F, int K,
+    const int* __restrict__ starts, const int* __restrict__ tmask, const int* __restrict__ fmask, int M, int tw, int fw,
+    float* __restrict__ x, float* __restrict__ y, int L, int pool) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [L][C*F + 1]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int CF = C * F, LD = CF + 1;
+    long s0 = starts[b];
+    if (s0 < 0) s0 = 0;
+    if (s0 + L > N) s0 = N - L;                                        // the reference's end-of-fold fallback
+    for (int i = tid; i < L * CF; i += 256) {
+        int t = i / CF, j = i - t * CF;
+        tile[t * LD + j] = mel[(s0 + t) * CF + j];
+    }
+    __syncthreads();
+    float* xo = x + (size_t)b * CF * L;
+    for (int i = tid; i < CF * L; i += 256) {
+        int j = i / L, t = i - j * L;                                  // j = c*F + f
+        int f = j % F;
+        float v = tile[t * LD + j];
+        for (int m = 0; m < M; ++m) {
+            int t0 = tmask ? tmask[b * M + m] : -1, f0 = fmask ? fmask[b * M + m] : -1;
+            if ((t0 >= 0 && t >= t0 && t < t0 + tw) || (f0 >= 0 && f >= f0 && f < f0 + fw)) v = 0.f;
+        }
+        xo[i] = v;
+    }
+    const int Lo = L / pool;
+    for (int i = tid; i < Lo * K; i += 256) {
+        int to = i / K, k = i - to * K;
+        float m = -INFINITY;
+        for (int j = 0; j < pool; ++j) m = fmaxf(m, lab[(s0 + (long)to * pool + j) * K + k]);
+        y[(size_t)b * Lo * K + i] = m;
+    }
+}
+
+extern "C" int sed_window_batch(const float* mel, const float* lab, long N, int C, int F, int K, const int* starts,
+                                const int* tmask, const int* fmask, int n_masks, int time_w, int freq_w, float* x,
+                                float* y, int B, int L, int pool, void* stream) {
+    SED_REQUIRE(mel && lab && starts && x && y, "window_batch: null pointer");
+    SED_REQUIRE(N >= L && C > 0 && F > 0 && K > 0 && B > 0 && L > 0 && pool > 0 && L % pool == 0, "window_batch: bad sizes");
+    SED_REQUIRE(n_masks >= 0 && (n_masks == 0 || (tmask && fmask)), "window_batch: masks requested but not given");
+    size_t lds = (size_t)L * (C * F + 1) * sizeof(float);
+    SED_REQUIRE(lds <= 150 * 1024, "window_batch: window of %d x %d floats does not fit LDS", L, C * F);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)window_batch_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    window_batch_k<<<B, 256, lds, as_stream(stream)>>>(mel, lab, N, C, F, K, starts, n_masks ? tmask : nullptr,
+                                                       n_masks ? fmask : nullptr, n_masks, time_w, freq_w, x, y, L, pool);
+    SED_LAUNCH_CHECK("window_batch");
+    return 0;
+}
+
+// feat [N][C*F] -> out [N/S][C][F][S] (time_last=1: the network input layout) or [N/S][C][S][F] (utils.py layout).
+__global__ __launch_bounds__(256) void pack_sequences_k(const float* __restrict__ feat, int C, int F, int S,
+                                                        int time_last, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [S][C*F + 1]
+    const int n = blockIdx.x, tid = threadIdx.x, CF = C * F, LD = CF + 1;
+    for (int i = tid; i < S * CF; i += 256) {
+        int t = i / CF, j = i - t * CF;
+        tile[t * LD + j] = feat[((size_t)n * S + t) * CF + j];
+    }
+    __syncthreads();
+    float* o = out + (size_t)n * CF * S;
+    for (int i = tid; i < CF * S; i += 256) {
+        if (time_last) { int j = i / S, t = i - j * S; o[i] = tile[t * LD + j]; }
+        else { int c = i / (S * F), r = i - c * S * F, t = r / F, f = r - t * F; o[i] = tile[t * LD + c * F + f]; }
+    }
+}
+
+extern "C" int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_last, float* out, void* stream) {
+    SED_REQUIRE(feat && out && N >= S && C > 0 && F > 0 && S > 0, "pack_sequences: bad arguments");
+    size_t lds = (size_t)S * (C * F + 1) * sizeof(float);
+    SED_REQUIRE(lds <= 150 * 1024, "pack_sequences: sequence tile does not fit LDS");
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)pack_sequences_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    pack_sequences_k<<<(unsigned)(N / S), 256, lds, as_stream(stream)>>>(feat, C, F, S, time_last, out);
+    SED_LAUNCH_CHECK("pack_sequences");
+    return 0;
+}
+
+// per-column mean and population standard deviation (sklearn StandardScaler: ddof = 0, sigma 0 -> 1)
+#define CS_BLOCKS 256
+__global__ __launch_bounds__(256) void colstats_partial_k(const float* __restrict__ x, long N, int F, double* __restrict__ part) {
+    // block handles rows [r0, r1); thread (col, slice)
+    const int nsl = 256 / F > 0 ? 256 / F : 1;
+    const int col = threadIdx.x % F, sl = threadIdx.x / F;
+    long per = (N + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
+    double a = 0.0, q = 0.0;
+    if (sl < nsl)
+        for (long r = r0 + sl; r < r1; r += nsl) { double v = x[r * F + col]; a += v; q += v * v; }
+    __shared__ double s1[256], s2[256];
+    s1[threadIdx.x] = a; s2[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < F) {
+        double A = 0.0, Q = 0.0;
+        for (int s = 0; s < nsl; ++s) { A += s1[s * F + threadIdx.x]; Q += s2[s * F + threadIdx.x]; }
+        part[((size_t)blockIdx.x * 2) * F + threadIdx.x] = A;
+        part[((size_t)blockIdx.x * 2 + 1) * F + threadIdx.x] = Q;
+    }
+}
+__global__ void colstats_final_k(const double* __restrict__ part, int nb, long N, int F, float* mean, float* stdv) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    double A = 0.0, Q = 0.0;
+    for (int b = 0; b < nb; ++b) { A += part[((size_t)b * 2) * F + c]; Q += part[((size_t)b * 2 + 1) * F + c]; }
+    double m = A / (double)N, var = Q / (double)N - m * m;
+    if (var < 0.0) var = 0.0;
+    double sd = sqrt(var);
+    mean[c] = (float)m;
+    stdv[c] = sd == 0.0 ? 1.f : (float)sd;
+}
+
+extern "C" size_t sed_col_mean_std_workspace_bytes(int F) { return (size_t)CS_BLOCKS * 2 * F * sizeof(double); }
+
+extern "C" int sed_col_mean_std(const float* x, long N, int F, float* mean, float* stdv, void* workspace, void* stream) {
+    SED_REQUIRE(x && mean && stdv && workspace && N > 0 && F > 0 && F <= 256, "col_mean_std: bad arguments (F <= 256)");
+    hipStream_t s = as_stream(stream);
+    int nb = N < CS_BLOCKS ? (int)N : CS_BLOCKS;
+    colstats_partial_k<<<nb, 256, 0, s>>>(x, N, F, (double*)workspace);
+    SED_LAUNCH_CHECK("colstats_partial");
+    colstats_final_k<<<cdiv(F, 64), 64, 0, s>>>((const double*)workspace, nb, N, F, mean, stdv);
+    SED_LAUNCH_CHECK("colstats_final");
+    return 0;
+}

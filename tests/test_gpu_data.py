@@ -1,0 +1,109 @@
+"""SURVEY 8(f) rows on the GPU: window gather + label pooling + SpecAugment, sequence packing, StandardScaler fit,
+against the numpy oracle (oracle/data_ref.py) and the goldens captured from the imported reference (g7, g8)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def data():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sed_crnn_amd import data as d
+    return d
+
+
+def test_window_items_match_reference_dataset(data):
+    d = load_golden("g8_window_aug.npz")
+    ds = data.HitWindowSet(d["item_mel"], d["item_lab"])
+    x, y = ds.gather([int(d["item_start"]), int(d["item_pos_start"])])
+    assert x.shape == (2, 1, 40, 64) and y.shape == (2, 8, 1)
+    np.testing.assert_array_equal(x[0].cpu().numpy(), d["item_x"])
+    np.testing.assert_array_equal(y[0].cpu().numpy(), d["item_y"])
+    np.testing.assert_array_equal(x[1].cpu().numpy(), d["item_pos_x"])
+    np.testing.assert_array_equal(y[1].cpu().numpy(), d["item_pos_y"])
+    # end-of-fold fallback: a start too close to the end is clamped (decorte_datamodule.py:79-82)
+    xe, _ = ds.gather([299])
+    np.testing.assert_array_equal(xe[0, 0].cpu().numpy(), d["item_mel"][300 - 64:].T)
+
+
+def test_spec_augment_matches_reference_draws(data):
+    from oracle import data_ref
+    d = load_golden("g8_window_aug.npz")
+    for i in range(3):
+        rs = np.random.RandomState(int(d[f"aug_seed{i}"]))
+        t, f = data_ref.draw_spec_masks(rs, 40, 64)
+        ds = data.HitWindowSet(d[f"aug_in{i}"].T.copy(), np.zeros((64, 1), np.float32))
+        x, _ = ds.gather([0], np.asarray([t]), np.asarray([f]))
+        np.testing.assert_array_equal(x[0, 0].cpu().numpy(), d[f"aug_out{i}"])
+
+
+def test_sampler_balance_pooling_and_multichannel(data):
+    from oracle import data_ref
+    g7 = load_golden("g7_dataset.npz")
+    rng = np.random.default_rng(0)
+    mel = rng.standard_normal((400, 80)).astype(np.float32)            # 2 channels x 40 mel
+    ds = data.HitWindowSet(mel, g7["lab"], n_channels=2, augment=True, seed=3)
+    np.testing.assert_array_equal(ds.neg_starts, g7["neg_starts"])
+    np.testing.assert_array_equal(ds.pos_frames, g7["pos_frames"])
+    assert len(ds) == int(g7["len"])
+    idx = np.arange(64)
+    starts = ds.draw_starts(idx)
+    lab = g7["lab"][:, 0]
+    for i, s in zip(idx, starts):
+        assert 0 <= s <= 400 - 64
+        assert (lab[s:s + 64].max() == 1) == (i % 2 == 0)                # even: holds a positive, odd: clean negative
+    t, f = ds.draw_masks(64)
+    assert t.min() >= 0 and t.max() < 64 - 8 and f.min() >= 0 and f.max() < 40 - 8
+    x, y = ds.gather(starts, t, f)
+    for b in (0, 1, 17, 63):
+        xr, yr = data_ref.window_item(mel, g7["lab"], int(starts[b]), 64, 8, list(t[b]), list(f[b]), n_channels=2)
+        np.testing.assert_array_equal(x[b].cpu().numpy(), xr)
+        np.testing.assert_array_equal(y[b].cpu().numpy(), yr)
+    loader = data.GpuWindowLoader(ds, batch_size=8, shuffle=True, drop_last=True)
+    batches = list(loader)
+    assert len(batches) == len(ds) // 8 and batches[0][0].shape == (8, 2, 40, 64) and batches[0][0].is_cuda
+
+
+def test_pack_sequences_matches_utils(data):
+    d = load_golden("g8_window_aug.npz")
+    feat = torch.from_numpy(d["pack_feat"]).float().cuda()
+    out = data.pack_sequences(feat, 16, n_channels=2, time_last=False)
+    np.testing.assert_allclose(out.cpu().numpy(), d["pack_mc"].astype(np.float32), rtol=0, atol=0)
+    out_t = data.pack_sequences(feat, 16, n_channels=2, time_last=True)
+    np.testing.assert_array_equal(out_t.cpu().numpy(), d["pack_mc"].astype(np.float32).transpose(0, 1, 3, 2))
+    assert out.shape == (70 // 16, 2, 16, 40)
+
+
+def test_standard_scaler_fit_and_fused_transform(data):
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal((5000, 40)) * rng.uniform(0.5, 3, 40) + rng.uniform(-5, 5, 40)).astype(np.float32)
+    x[:, 7] = 2.5                                                        # constant column: sigma -> 1
+    mean, std = data.standard_scaler_fit(torch.from_numpy(x).cuda())
+    np.testing.assert_allclose(mean.cpu().numpy(), x.astype(np.float64).mean(0), rtol=1e-5, atol=1e-5)
+    ref_sd = x.astype(np.float64).std(0)
+    ref_sd[7] = 1.0
+    np.testing.assert_allclose(std.cpu().numpy(), ref_sd, rtol=1e-4, atol=1e-5)
+
+
+def test_run_epoch_on_gpu_loader(data):
+    """the fit loop consumes the device loader unchanged (run_epoch signature of sed.py:128-141)"""
+    import sed_crnn_amd as sed
+    rng = np.random.default_rng(2)
+    mel = rng.standard_normal((600, 40)).astype(np.float32)
+    lab = np.zeros((600, 1), np.float32)
+    lab[100:110] = 1
+    lab[400:420] = 1
+    ds = data.HitWindowSet(mel, lab, augment=True, seed=1)
+    loader = data.GpuWindowLoader(ds, batch_size=16, shuffle=True, drop_last=True)
+    torch.manual_seed(0)
+    m = sed.TimePooledCRNN(conv_channels=16, dropout=0.1, gru_hidden=16).cuda()
+    opt = sed.FusedAdam(m.parameters(), lr=1e-3)
+    l0, p, t = sed.run_epoch(m, loader, sed.BCEWithLogitsLoss(), opt)
+    assert p.shape == (len(loader) * 16, 8, 1) and t.shape == p.shape and np.isfinite(l0)
+    sc = sed.metrics.compute_scores(p > 0.5, t, frames_in_1_sec=5)
+    assert set(sc) == {"f1_overall_1sec", "er_overall_1sec"}

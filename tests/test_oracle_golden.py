@@ -120,3 +120,26 @@ def test_g6_metrics_known_answers():
     assert np.isinf(metrics_ref.er_1sec(o, z, 5)) and np.isinf(d["edge_nref0_nsys_er"])
     assert np.isnan(metrics_ref.er_1sec(z, z, 5)) and np.isnan(d["edge_allzero_er"])
     assert metrics_ref.f1_1sec(z, z, 5) == float(d["edge_allzero_f1"])
+
+
+def test_g7_g8_dataset_augment_and_packing_oracle():
+    """oracle/data_ref.py against what the imported reference produced (HitWindowDataset items, _spec_augment under a
+    seeded np.random, utils.split_in_seqs / split_multi_channels, clean negatives, label pooling)"""
+    from oracle import data_ref as R
+    d = load_golden("g8_window_aug.npz")
+    for i in range(3):
+        rs = np.random.RandomState(int(d[f"aug_seed{i}"]))
+        t, f = R.draw_spec_masks(rs, 40, 64)
+        np.testing.assert_array_equal(R.spec_augment(d[f"aug_in{i}"], t, f), d[f"aug_out{i}"])
+    x, y = R.window_item(d["item_mel"], d["item_lab"], int(d["item_start"]), 64, 8)
+    np.testing.assert_array_equal(x, d["item_x"])
+    np.testing.assert_array_equal(y, d["item_y"])
+    x, y = R.window_item(d["item_mel"], d["item_lab"], int(d["item_pos_start"]), 64, 8)
+    np.testing.assert_array_equal(x, d["item_pos_x"])
+    np.testing.assert_array_equal(y, d["item_pos_y"])
+    assert y.max() == 1.0
+    np.testing.assert_array_equal(R.split_in_seqs(d["pack_feat"], 16), d["pack_seqs"])
+    np.testing.assert_array_equal(R.split_multi_channels(d["pack_seqs"], 2), d["pack_mc"])
+    g7 = load_golden("g7_dataset.npz")
+    np.testing.assert_array_equal(R.find_clean_negatives(g7["lab"], 64), g7["neg_starts"])
+    np.testing.assert_array_equal(R.pool_labels(g7["lab"][60:124], 8), g7["pooled_60"])
