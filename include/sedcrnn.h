@@ -258,11 +258,17 @@ int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float
                     void* workspace, int training, uint64_t seed, void* stream);
 /* Gradients of every parameter into `g` (same layouts as `p`; written, not accumulated).
  * Stages let the host overlap the gradient all-reduce with the rest of backward:
- *   stage 0 = dense head + GRU stack, stage s>=1 = conv block (n_conv - s).  Run stages
- *   [stage_begin, stage_end) in increasing order; (0, n_conv+1) = everything. */
+ *   stage 0 = dense head + GRU stack, stage s>=1 = conv block l = n_conv - s.  Run stages
+ *   [stage_begin, stage_end) in increasing order; (0, n_conv+1) = everything.
+ * When stage s returns, every gradient of that stage (block l: conv weight/bias, BatchNorm gamma/beta) is complete on
+ * `stream`.
+ * aux_stream (NULL or == stream: serial): a second hipStream_t.  The stage of block l then issues the HBM-bound
+ * BatchNorm/ReLU/pool backward of block l-1 (for a fused first block: all of block 0) on it, beside block l's
+ * MFMA-bound weight gradient on `stream`; the stage of block l-1 starts by waiting for it (hipEvents).  Stages must
+ * therefore be run in order with the same aux_stream for the whole backward. */
 int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
                      const float* x, const float* dlogits, void* workspace, uint64_t seed,
-                     int stage_begin, int stage_end, void* stream);
+                     int stage_begin, int stage_end, void* stream, void* aux_stream);
 
 /* ───────────── in-library kernel timers (measurement only; off by default) ─────────────
  * When a tag's bit is set in `tag_mask`, every launch of that kernel family is bracketed by a pair of

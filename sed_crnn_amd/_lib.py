@@ -94,7 +94,7 @@ SIGNATURES = {
     "sed_net_out_shape": (_i, [C.POINTER(NetCfg), C.POINTER(_i), C.POINTER(_i)]),
     "sed_net_workspace_bytes": (_sz, [C.POINTER(NetCfg), _i]),
     "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _stream]),
-    "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _stream]),
+    "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _stream, _stream]),
 }
 
 _lib = None

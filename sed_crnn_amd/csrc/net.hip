@@ -24,7 +24,7 @@ struct Layout {
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
-    size_t bn_part, sum_g, sum_gx, dbias_part, dconv, gradA, wgrad_ws, dgi, dgh, gru_bws, dgout[SED_MAX_GRU];
+    size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, c1_ws, dgi, dgh, gru_bws, dgout[SED_MAX_GRU];
     size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws;
     size_t total;     // floats
 };
@@ -44,7 +44,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
     Carver cv;
     int Cin = c->Cin, T = c->T, F = c->F;
-    size_t max_conv = 0, max_pool = 0, max_wgrad = 0;
+    size_t max_pool = 0, max_wgrad = 0, c1_ws = 64;
     int max_bn_rows = 0, maxC = 0;
     for (int l = 0; l < c->n_conv; ++l) {
         ConvL& q = L->cv[l];
@@ -71,11 +71,12 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->stat[l] = cv.take((size_t)q.rows * 2 * q.C);
         L->mean[l] = cv.take(q.C); L->rstd[l] = cv.take(q.C); L->scale[l] = cv.take(q.C); L->shift[l] = cv.take(q.C);
         L->pooled[l] = cv.take(npool);
-        if (nout > max_conv) max_conv = nout;
         if (npool > max_pool) max_pool = npool;
-        size_t wg = (q.fused ? sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C)
-                             : sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C)) / sizeof(float);
-        if (wg > max_wgrad) max_wgrad = wg;
+        if (q.fused) c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
+        else {
+            size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
+            if (wg > max_wgrad) max_wgrad = wg;
+        }
         if (q.bn_rows > max_bn_rows) max_bn_rows = q.bn_rows;
         if (q.C > maxC) maxC = q.C;
         Cin = q.C; T = q.Tp; F = q.Fp;
@@ -108,10 +109,14 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->bn_part = cv.take((size_t)max_bn_rows * 2 * maxC);
         L->sum_g = cv.take(maxC); L->sum_gx = cv.take(maxC);
         L->dbias_part = cv.take((size_t)max_bn_rows * maxC);
-        L->dconv = cv.take(max_conv);
+        // one gradient buffer per conv block: the weight gradient of block l (auxiliary stream) may still read dconv[l]
+        // while the main stream already writes dconv[l-1]
+        for (int l = 0; l < c->n_conv; ++l)
+            L->dconv[l] = L->cv[l].fused ? 0 : cv.take((size_t)c->B * L->cv[l].T * L->cv[l].F * L->cv[l].C);
         size_t ga = max_pool > M * (size_t)L->feat ? max_pool : M * (size_t)L->feat;
         L->gradA = cv.take(ga);
-        L->wgrad_ws = cv.take(max_wgrad);
+        L->wgrad_ws = cv.take(max_wgrad + 64);
+        L->c1_ws = cv.take(c1_ws);
         L->dgi = cv.take(M * 6 * maxH);
         L->dgh = cv.take(M * 6 * maxH);
         L->gru_bws = cv.take(sed_gru_seq_bwd_workspace_bytes(c->B, maxH) / sizeof(float));
@@ -222,8 +227,24 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
 
 extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
                                 const float* x, const float* dlogits, void* workspace, uint64_t seed,
-                                int stage_begin, int stage_end, void* stream) {
+                                int stage_begin, int stage_end, void* stream, void* aux_stream) {
     SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward: null pointer");
+    // cross-stream ordering (host objects, created once): ev_dg[l] = data gradient of block l complete (main stream),
+    // ev_bn[l] = BatchNorm backward of block l complete (auxiliary stream)
+    static hipEvent_t ev_dg[SED_MAX_CONV] = {}, ev_bn[SED_MAX_CONV] = {};
+    hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
+    if (s_aux && s_aux != s_main) {
+        for (int l = 0; l < SED_MAX_CONV; ++l)
+            if (!ev_dg[l]) {
+                if (hipEventCreateWithFlags(&ev_dg[l], hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ev_bn[l], hipEventDisableTiming) != hipSuccess) {
+                    sed_set_error("net_backward: hipEventCreate failed");
+                    return SED_EINVAL;
+                }
+            }
+    } else {
+        s_aux = nullptr;
+    }
     Layout L;
     SED_TRY(build_layout(c, 1, &L));
     SED_REQUIRE(stage_begin >= 0 && stage_end <= L.n_conv + 1 && stage_begin < stage_end,
@@ -275,36 +296,52 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
     }
     // ── conv blocks, last to first ──
-    for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
-        const int l = L.n_conv - s;
+    // BatchNorm/ReLU/pool/dropout backward of block l (for the fused first block: everything of block 0) on stream `st`
+    auto bn_passes = [&](int l, void* st) -> int {
         const ConvL& q = L.cv[l];
         const int last = (l == L.n_conv - 1);
-        const float drop = q.drop;
         const uint64_t sd = layer_seed(seed, l);
         SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
         if (q.fused) {
             SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                          ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
-                                         drop, sd, stream));
-            SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], stream));
+                                         q.drop, sd, st));
+            SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], st));
             SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                               ws + L.mean[l], ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, g->conv_w[l],
-                                              g->conv_b[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, drop, sd, stream));
-            continue;
+                                              g->conv_b[l], ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, st));
+            return 0;
         }
         const float* y = ws + L.conv_out[l];
         SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
                                                  ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last,
-                                                 drop, sd, stream));
-        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], stream));
+                                                 q.drop, sd, st));
+        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], st));
         SED_TRY(sed_bn_relu_pool_drop_bwd_apply(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
-                                                ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, ws + L.dconv,
-                                                ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, drop, sd, stream));
-        SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], stream));
+                                                ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, ws + L.dconv[l],
+                                                ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, sd, st));
+        SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], st));
+        return 0;
+    };
+    for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
+        const int l = L.n_conv - s;
+        const ConvL& q = L.cv[l];
+        // With an auxiliary stream the HBM-bound BN backward of block l was issued there by the stage of block l+1,
+        // beside that block's MFMA-bound weight gradient; the top block (and the serial mode) runs it here.
+        if (s_aux && l < L.n_conv - 1) (void)hipStreamWaitEvent(s_main, ev_bn[l], 0);
+        else SED_TRY(bn_passes(l, stream));
+        if (q.fused) continue;                       // block 0 fused: bn_passes already produced every gradient
+        if (l > 0) {   // data gradient = the same convolution with flipped, transposed taps
+            SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+            if (s_aux) {
+                (void)hipEventRecord(ev_dg[l], s_main);
+                (void)hipStreamWaitEvent(s_aux, ev_dg[l], 0);
+                SED_TRY(bn_passes(l - 1, aux_stream));
+                (void)hipEventRecord(ev_bn[l - 1], s_aux);
+            }
+        }
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
-        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv, g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
-        if (l > 0)   // data gradient = the same convolution with flipped, transposed taps
-            SED_TRY(sed_conv3x3_fwd(ws + L.dconv, 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
     }
     return 0;
 }

@@ -135,6 +135,8 @@ class HipCRNN(nn.Module):
             f //= pf
         self.flat_features = conv_channels[-1] * f
         self.time_factor = math.prod(pt for _, pt in self.pools)
+        self.overlap_wgrad = True        # BN backward of block l-1 on an auxiliary stream beside block l's weight gradient
+        self._aux_stream = None
         self._ticket = 0
         self._seed_counter = 0
         self._nbt_pending = 0
@@ -167,7 +169,7 @@ class HipCRNN(nn.Module):
                 off += (p.numel() + 3) // 4 * 4
         place(order)
         stage_ends.append(off)
-        for l in range(nconv - 1, -1, -1):
+        for l in range(nconv - 1, -1, -1):              # conv stage s = block l = nconv - s
             ps = [r["conv_w"][l], r["conv_b"][l], r["bn_g"][l], r["bn_b"][l]]
             order += ps
             place(ps)
@@ -309,8 +311,11 @@ class HipCRNN(nn.Module):
         P, G = self._param_structs()
         if stage_end is None:
             stage_end = len(self.conv_channels) + 1
+        if getattr(self, "_aux_stream", None) is None or self._aux_stream.device != x.device:
+            self._aux_stream = torch.cuda.Stream(device=x.device)
+        aux = C.c_void_p(self._aux_stream.cuda_stream) if self.overlap_wgrad else None
         check(lib().sed_net_backward(C.byref(cfg), C.byref(P), C.byref(G), _lib.ptr(x), _lib.ptr(dlogits),
-                                     _lib.ptr(ws), self._seed, stage_begin, stage_end, _lib.stream_ptr()),
+                                     _lib.ptr(ws), self._seed, stage_begin, stage_end, _lib.stream_ptr(), aux),
               "sed_net_backward")
 
     # ── nn.Module surface ──
