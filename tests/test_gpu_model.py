@@ -230,6 +230,30 @@ def test_multichannel_configs_vs_oracle(sed, cin, mel, T, H, C):
     _oracle_vs_hip(sed, ref, m, x, y)
 
 
+@pytest.mark.parametrize("B,T,C,H", [(1, 8, 8, 8), (3, 24, 8, 16), (2, 40, 16, 8), (5, 72, 8, 32), (7, 8, 128, 128)])
+def test_ragged_batch_and_sequence_shapes_vs_oracle(sed, B, T, C, H):
+    """smallest legal sequence (T = 8 -> one GRU step), batch 1, batch sizes that do not fill a GRU batch tile or a conv
+    time tile, odd numbers of conv tiles"""
+    from oracle import crnn_ref
+    torch.manual_seed(B * 100 + T)
+    ref = crnn_ref.SedNetRef(conv_channels=C, dropout=0.0, gru_hidden=H)
+    m = sed.TimePooledCRNN(conv_channels=C, dropout=0.0, gru_hidden=H)
+    x, y = crnn_ref.synthetic_batch(B, 1, 40, T, T // 8, seed=B + T)
+    if B * T * 40 < 4096:             # tiny batches make BatchNorm's 1/sigma large: keep the comparison well conditioned
+        x = x * 3.0
+    _oracle_vs_hip(sed, ref, m, x, y)
+
+
+def test_multiclass_head_and_focal_sum(sed):
+    """K = 6 classes (README figure) through the time-pooled topology; label tensor [B,T',6]"""
+    from oracle import crnn_ref
+    torch.manual_seed(21)
+    ref = crnn_ref.SedNetRef(conv_channels=16, dropout=0.0, gru_hidden=16, n_classes=6)
+    m = sed.TimePooledCRNN(conv_channels=16, dropout=0.0, gru_hidden=16, n_classes=6)
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 32, 4, K=6, seed=3)
+    _oracle_vs_hip(sed, ref, m, x, y)
+
+
 def test_lightning_variant_vs_oracle_focal(sed):
     from oracle import crnn_ref
     torch.manual_seed(8)
