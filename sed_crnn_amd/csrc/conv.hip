@@ -672,30 +672,42 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
     f32x4 px[DB ? WG_NX : 1], pd[DB ? WG_ND : 1];
-    auto fetch = [&](int tile) {          // global -> registers
-        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+    // tile-invariant part of the staging addresses, computed once per block: element offset from the tile origin
+    // (b, t0, f = 0) and the time row it belongs to (-1: padding or out of the tile); per tile only a base pointer,
+    // one add and one range test per float4 remain (the index math otherwise runs with the MFMA pipe idle)
+    int xo[DB ? WG_NX : 1], xt[DB ? WG_NX : 1], dofs[DB ? WG_ND : 1], dt[DB ? WG_ND : 1];
+    if (DB) {
 #pragma unroll
         for (int u = 0; u < WG_NX; ++u) {
-            int i = tid + u * 256;
+            int i = tid + u * 256, row = i >> 3, q = i & 7;
+            int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+            bool ok = i < HR * 8 && ff >= 1 && ff <= F;
+            xt[u] = ok ? tt - 1 : -(1 << 20);
+            xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < WG_ND; ++u) {
+            int i = tid + u * 256, row = i >> 5, q = i & 31;
+            int tl = sed_fdiv(row, invF);
+            dt[u] = (i < MROWS * 32) ? tl : (1 << 20);
+            dofs[u] = row * Cout + co0 + q * 4;                     // (tl*F + f) == row
+        }
+    }
+    auto fetch = [&](int tile) {          // global -> registers
+        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+        const float* xb = x + ((size_t)b * T + t0) * F * Cin;
+        const float* db = dy + ((size_t)b * T + t0) * F * Cout;
+#pragma unroll
+        for (int u = 0; u < WG_NX; ++u) {
             f32x4 v = {0, 0, 0, 0};
-            if (i < HR * 8) {
-                int row = i >> 3, q = i & 7;
-                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-                int t = t0 + tt - 1, f = ff - 1;
-                if (t >= 0 && t < T && f >= 0 && f < F)
-                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
-            }
+            int t = t0 + xt[u];
+            if (t >= 0 && t < T) v = *(const f32x4*)(xb + xo[u]);
             px[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < WG_ND; ++u) {
-            int i = tid + u * 256;
             f32x4 v = {0, 0, 0, 0};
-            if (i < MROWS * 32) {
-                int row = i >> 5, q = i & 31;
-                int tl = sed_fdiv(row, invF), f = row - tl * F;
-                if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
-            }
+            if (t0 + dt[u] < T) v = *(const f32x4*)(db + dofs[u]);
             pd[u] = v;
         }
     };
