@@ -77,6 +77,12 @@ int sed_bn_finalize_train(const float* stat_partials, int rows, int C, double co
                           const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps,
                           float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* The same in two steps, for synchronised BatchNorm across ranks: sums[2C] = (sum x, sum x^2) of this rank's partials;
+ * the host all-reduces (SUM) the 2C floats; finalize_from_sums then uses the GLOBAL element count. */
+int sed_bn_stat_sums(const float* stat_partials, int rows, int C, float* sums, void* stream);
+int sed_bn_finalize_from_sums(const float* sums, int C, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              float* mean, float* rstd, float* scale, float* shift, void* stream);
 /* Eval: scale/shift from the running statistics. */
 int sed_bn_finalize_eval(const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, int C,
@@ -183,6 +189,7 @@ int sed_loss_fwd_bwd(const float* logits, const float* targets, int n, int kind,
                      float gamma, int reduction_mean, float* loss, float* dlogits, float* probs,
                      void* stream);
 int sed_sigmoid(const float* x, float* y, int n, void* stream);
+int sed_scale(float* x, long n, float alpha, void* stream);        /* x *= alpha */
 
 /* ───────────── optimiser (torch.optim.Adam sed.py:159; crnn_lightning.py:195-197; clip train_lightning.py:50) ─────────────
  * sq-norm: norm_out[0] = ||g||_2, norm_out[1] = clip coefficient min(1, max_norm/(norm+1e-6))
@@ -269,6 +276,24 @@ int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float
 int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
                      const float* x, const float* dlogits, void* workspace, uint64_t seed,
                      int stage_begin, int stage_end, void* stream, void* aux_stream);
+
+/* Phased execution, for synchronised BatchNorm in data-parallel training: the per-block statistics
+ * are the only cross-sample coupling besides the loss mean, so the plan can stop at them.
+ *   forward phases : 2l   = conv block l + its statistic sums (training),
+ *                    2l+1 = finalise with count*count_scale, normalise/ReLU/pool/dropout,
+ *                    2*n_conv = GRU stack + dense head.
+ *   backward phases: 0    = dense head + GRU stack,
+ *                    2k+1 = BatchNorm-backward sums (sum g, sum g*xhat) of block l = n_conv-1-k,
+ *                    2k+2 = rest of block l (apply, weight/bias/data gradients); its gradients are then complete.
+ * Between phase 2l and 2l+1 (forward) / 2k+1 and 2k+2 (backward) the host all-reduces (SUM) the workspace region
+ * sed_net_sync_region() names; count_scale = number of ranks (1 = unsynchronised).  Single stream, no overlap. */
+int sed_net_sync_region(const sed_net_cfg* cfg, int backward, int block, size_t* offset_bytes, size_t* n_floats);
+int sed_net_forward_phases(const sed_net_cfg* cfg, const sed_net_params* p, const float* x, float* logits,
+                           void* workspace, int training, uint64_t seed, int phase_begin, int phase_end,
+                           float count_scale, void* stream);
+int sed_net_backward_phases(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
+                            const float* x, const float* dlogits, void* workspace, uint64_t seed,
+                            int phase_begin, int phase_end, float count_scale, void* stream);
 
 /* ───────────── in-library kernel timers (measurement only; off by default) ─────────────
  * When a tag's bit is set in `tag_mask`, every launch of that kernel family is bracketed by a pair of

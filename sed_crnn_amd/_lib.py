@@ -61,6 +61,8 @@ SIGNATURES = {
     "sed_conv1_bwd_apply_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
     "sed_bn_finalize_train": (_i, [_fp, _i, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
+    "sed_bn_stat_sums": (_i, [_fp, _i, _i, _fp, _stream]),
+    "sed_bn_finalize_from_sums": (_i, [_fp, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
     "sed_bn_finalize_eval": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _stream]),
     "sed_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
     "sed_bn_bwd_rows": (_i, [_i, _i, _i]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "sed_gru_seq_bwd": (_i, [_fp, _fp, _pp, _fp, _fp, _pp, _pp, _fp, _i, _i, _i, _stream]),
     "sed_loss_fwd_bwd": (_i, [_fp, _fp, _i, _i, _f, _f, _i, _fp, _fp, _fp, _stream]),
     "sed_sigmoid": (_i, [_fp, _fp, _i, _stream]),
+    "sed_scale": (_i, [_fp, _l, _f, _stream]),
     "sed_sqnorm_workspace_bytes": (_sz, [_l]),
     "sed_grad_norm_clip_coef": (_i, [_fp, _l, _f, _fp, _fp, _stream]),
     "sed_adam_step": (_i, [_fp, _fp, _fp, _fp, _l, _f, _f, _f, _f, _f, _i, _fp, _stream]),
@@ -94,6 +97,9 @@ SIGNATURES = {
     "sed_net_out_shape": (_i, [C.POINTER(NetCfg), C.POINTER(_i), C.POINTER(_i)]),
     "sed_net_workspace_bytes": (_sz, [C.POINTER(NetCfg), _i]),
     "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _stream]),
+    "sed_net_sync_region": (_i, [C.POINTER(NetCfg), _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "sed_net_forward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _i, _i, _f, _stream]),
+    "sed_net_backward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _f, _stream]),
     "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _stream, _stream]),
 }
 

@@ -72,6 +72,66 @@ extern "C" int sed_bn_finalize_train(const float* part, int rows, int C, double 
     return 0;
 }
 
+// sums[0..C) = sum x, sums[C..2C) = sum x^2 over all partial rows (fixed order, double accumulation)
+__global__ __launch_bounds__(1024) void bn_stat_sums_k(const float* __restrict__ part, int rows, int C, float* __restrict__ sums) {
+    __shared__ double s1[32][33], s2[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = sl; r < rows; r += 32) {
+            a += (double)part[(size_t)r * 2 * C + c];
+            q += (double)part[(size_t)r * 2 * C + C + c];
+        }
+    s1[sl][cl] = a;
+    s2[sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double A = 0.0, Q = 0.0;
+        for (int s = 0; s < 32; ++s) { A += s1[s][cl]; Q += s2[s][cl]; }
+        sums[c] = (float)A;
+        sums[C + c] = (float)Q;
+    }
+}
+
+__global__ void bn_finalize_from_sums_k(const float* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                        float momentum, float eps, float* mean_o, float* rstd_o, float* scale_o, float* shift_o) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double m = (double)sums[c] / count;
+    double var = (double)sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_o[c] = (float)m;
+    rstd_o[c] = rstd;
+    float sc = gamma[c] * rstd;
+    scale_o[c] = sc;
+    shift_o[c] = beta[c] - (float)m * sc;
+    if (rmean) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int sed_bn_stat_sums(const float* part, int rows, int C, float* sums, void* stream) {
+    SED_REQUIRE(part && sums && rows > 0 && C > 0, "bn_stat_sums: bad arguments");
+    bn_stat_sums_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(part, rows, C, sums);
+    SED_LAUNCH_CHECK("bn_stat_sums");
+    return 0;
+}
+
+extern "C" int sed_bn_finalize_from_sums(const float* sums, int C, double count, const float* gamma, const float* beta,
+                                         float* rmean, float* rvar, float momentum, float eps, float* mean, float* rstd,
+                                         float* scale, float* shift, void* stream) {
+    SED_REQUIRE(sums && gamma && beta && mean && rstd && scale && shift && C > 0 && count > 0, "bn_finalize_from_sums: bad arguments");
+    bn_finalize_from_sums_k<<<cdiv(C, 128), 128, 0, as_stream(stream)>>>(sums, C, count, gamma, beta, rmean, rvar, momentum, eps,
+                                                                        mean, rstd, scale, shift);
+    SED_LAUNCH_CHECK("bn_finalize_from_sums");
+    return 0;
+}
+
 __global__ void bn_finalize_eval_k(const float* g, const float* b, const float* rm, const float* rv, float eps,
                                    int C, float* scale, float* shift) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -69,6 +69,18 @@ extern "C" int sed_sigmoid(const float* x, float* y, int n, void* stream) {
     return 0;
 }
 
+__global__ void scale_k(float* __restrict__ x, long n, float alpha) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= alpha;
+}
+
+extern "C" int sed_scale(float* x, long n, float alpha, void* stream) {
+    SED_REQUIRE(x && n > 0, "scale: bad arguments");
+    scale_k<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(x, n, alpha);
+    SED_LAUNCH_CHECK("scale");
+    return 0;
+}
+
 // ───────────────────────── grad norm + clip coefficient ─────────────────────────
 #define SQN_BLOCKS 512
 __global__ __launch_bounds__(256) void sqnorm_partial_k(const float* __restrict__ g, long n, double* __restrict__ part) {

@@ -20,7 +20,7 @@ struct Layout {
     // float offsets into the workspace
     size_t wp_f[SED_MAX_CONV], wp_d[SED_MAX_CONV], conv_out[SED_MAX_CONV], stat[SED_MAX_CONV];
     size_t mean[SED_MAX_CONV], rstd[SED_MAX_CONV], scale[SED_MAX_CONV], shift[SED_MAX_CONV];
-    size_t pooled[SED_MAX_CONV];
+    size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV];
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
@@ -71,6 +71,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->stat[l] = cv.take((size_t)q.rows * 2 * q.C);
         L->mean[l] = cv.take(q.C); L->rstd[l] = cv.take(q.C); L->scale[l] = cv.take(q.C); L->shift[l] = cv.take(q.C);
         L->pooled[l] = cv.take(npool);
+        L->bn_sums[l] = cv.take((size_t)2 * q.C);
         if (npool > max_pool) max_pool = npool;
         if (q.fused) c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
         else {
@@ -107,7 +108,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     }
     if (training) {
         L->bn_part = cv.take((size_t)max_bn_rows * 2 * maxC);
-        L->sum_g = cv.take(maxC); L->sum_gx = cv.take(maxC);
+        L->sum_g = cv.take((size_t)2 * maxC); L->sum_gx = 0;     // sum_gx = sum_g + C of the block (one all-reduce region)
         L->dbias_part = cv.take((size_t)max_bn_rows * maxC);
         // one gradient buffer per conv block: the weight gradient of block l (auxiliary stream) may still read dconv[l]
         // while the main stream already writes dconv[l-1]
@@ -154,30 +155,44 @@ extern "C" size_t sed_net_workspace_bytes(const sed_net_cfg* cfg, int training) 
     return L.total * sizeof(float);
 }
 
-extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
-                               void* workspace, int training, uint64_t seed, void* stream) {
+// phases [pb, pe): 2l = conv block l (+ statistic sums), 2l+1 = finalise + normalise/pool, 2*n_conv = GRU + head
+static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits, void* workspace,
+                        int training, uint64_t seed, int pb, int pe, float count_scale, void* stream) {
     SED_REQUIRE(p && x && logits && workspace, "net_forward: null pointer");
     Layout L;
     SED_TRY(build_layout(c, training, &L));
+    SED_REQUIRE(pb >= 0 && pe <= 2 * L.n_conv + 1 && pb < pe, "net_forward: bad phase range [%d,%d)", pb, pe);
     float* ws = (float*)workspace;
     const int B = c->B;
-    const float* in = x;
     for (int l = 0; l < L.n_conv; ++l) {
         const ConvL& q = L.cv[l];
+        const float* in = (l == 0) ? x : ws + L.pooled[l - 1];
+        const bool do_a = pb <= 2 * l && 2 * l < pe, do_b = pb <= 2 * l + 1 && 2 * l + 1 < pe;
+        if (!do_a && !do_b) continue;
+        const bool one_shot = do_a && do_b && count_scale == 1.f;      // unsynchronised: the fused finalise kernel
         SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
                     "net_forward: missing parameters of conv block %d", l);
-        SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
-                                         q.C, q.Cin, stream));
-        if (q.fused) {
-            if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], B, q.Cin, q.F, q.T, q.C, stream));
-        } else {
-            SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
-                                    training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+        if (do_a) {
+            SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
+                                             q.C, q.Cin, stream));
+            if (q.fused) {
+                if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], B, q.Cin, q.F, q.T, q.C, stream));
+            } else {
+                SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
+                                        training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+            }
+            if (training && !one_shot) SED_TRY(sed_bn_stat_sums(ws + L.stat[l], q.rows, q.C, ws + L.bn_sums[l], stream));
         }
-        if (training)
-            SED_TRY(sed_bn_finalize_train(ws + L.stat[l], q.rows, q.C, (double)B * q.T * q.F, p->bn_g[l], p->bn_b[l],
+        if (!do_b) continue;
+        const double count = (double)B * q.T * q.F;
+        if (training && one_shot)
+            SED_TRY(sed_bn_finalize_train(ws + L.stat[l], q.rows, q.C, count, p->bn_g[l], p->bn_b[l],
                                           p->bn_rm[l], p->bn_rv[l], c->bn_momentum, c->bn_eps, ws + L.mean[l],
                                           ws + L.rstd[l], ws + L.scale[l], ws + L.shift[l], stream));
+        else if (training)
+            SED_TRY(sed_bn_finalize_from_sums(ws + L.bn_sums[l], q.C, count * (double)count_scale, p->bn_g[l], p->bn_b[l],
+                                              p->bn_rm[l], p->bn_rv[l], c->bn_momentum, c->bn_eps, ws + L.mean[l],
+                                              ws + L.rstd[l], ws + L.scale[l], ws + L.shift[l], stream));
         else
             SED_TRY(sed_bn_finalize_eval(p->bn_g[l], p->bn_b[l], p->bn_rm[l], p->bn_rv[l], c->bn_eps, q.C,
                                          ws + L.scale[l], ws + L.shift[l], stream));
@@ -190,8 +205,8 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
             SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
                                               q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
                                               layer_seed(seed, l), stream));
-        in = ws + L.pooled[l];
     }
+    if (pe <= 2 * L.n_conv) return 0;
     const int M = L.M;
     const float* gin = ws + L.pooled[L.n_conv - 1];          // [M][C*F'] in the reference feature order
     for (int i = 0; i < L.n_gru; ++i) {
@@ -221,6 +236,65 @@ extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, co
         float* y = last ? logits : ws + L.act[j];
         SED_TRY(sed_linear_fwd(din, p->dense_w[j], p->dense_b[j], y, M, L.dK[j], L.dN[j], !last, stream));
         din = y;
+    }
+    return 0;
+}
+
+extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
+                               void* workspace, int training, uint64_t seed, void* stream) {
+    return forward_impl(c, p, x, logits, workspace, training, seed, 0, 2 * (c ? c->n_conv : 0) + 1, 1.f, stream);
+}
+
+extern "C" int sed_net_forward_phases(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
+                                      void* workspace, int training, uint64_t seed, int phase_begin, int phase_end,
+                                      float count_scale, void* stream) {
+    SED_REQUIRE(count_scale >= 1.f, "net_forward_phases: count_scale must be >= 1");
+    return forward_impl(c, p, x, logits, workspace, training, seed, phase_begin, phase_end, count_scale, stream);
+}
+
+extern "C" int sed_net_sync_region(const sed_net_cfg* c, int backward, int block, size_t* offset_bytes, size_t* n_floats) {
+    Layout L;
+    SED_TRY(build_layout(c, 1, &L));
+    SED_REQUIRE(block >= 0 && block < L.n_conv && offset_bytes && n_floats, "net_sync_region: bad arguments");
+    *offset_bytes = (backward ? L.sum_g : L.bn_sums[block]) * sizeof(float);
+    *n_floats = (size_t)2 * L.cv[block].C;
+    return 0;
+}
+
+// BatchNorm/ReLU/pool/dropout backward of block l on stream `st` (for the fused first block: everything of block 0).
+// part 1 = reduction pass (sum g, sum g*xhat -> ws.sum_g[0..2C), dgamma, dbeta), part 2 = apply pass (dconv[l] + conv-bias
+// gradient; fused block: + weight gradient), 3 = both.  count_scale > 1: the sums were all-reduced over that many ranks.
+static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
+                       const float* x, float* ws, uint64_t seed, int l, int part, float count_scale, void* st) {
+    const ConvL& q = L.cv[l];
+    const int B = c->B, last = (l == L.n_conv - 1);
+    const uint64_t sd = layer_seed(seed, l);
+    SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
+    float* sum_g = ws + L.sum_g;
+    float* sum_gx = sum_g + q.C;
+    if (part & 1) {
+        if (q.fused)
+            SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                         ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
+                                         q.drop, sd, st));
+        else
+            SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                                     ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf,
+                                                     q.pt, last, q.drop, sd, st));
+        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, sum_g, sum_gx, g->bn_g[l], g->bn_b[l], st));
+    }
+    if (part & 2) {
+        if (count_scale != 1.f) SED_TRY(sed_scale(sum_g, 2 * q.C, 1.f / count_scale, st));   // global sums / global count
+        if (q.fused) {
+            SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                              ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
+                                              ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, st));
+        } else {
+            SED_TRY(sed_bn_relu_pool_drop_bwd_apply(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
+                                                    ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, ws + L.dconv[l],
+                                                    ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, sd, st));
+            SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], st));
+        }
     }
     return 0;
 }
@@ -296,33 +370,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
     }
     // ── conv blocks, last to first ──
-    // BatchNorm/ReLU/pool/dropout backward of block l (for the fused first block: everything of block 0) on stream `st`
-    auto bn_passes = [&](int l, void* st) -> int {
-        const ConvL& q = L.cv[l];
-        const int last = (l == L.n_conv - 1);
-        const uint64_t sd = layer_seed(seed, l);
-        SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
-        if (q.fused) {
-            SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
-                                         ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
-                                         q.drop, sd, st));
-            SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], st));
-            SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
-                                              ws + L.mean[l], ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, g->conv_w[l],
-                                              g->conv_b[l], ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, st));
-            return 0;
-        }
-        const float* y = ws + L.conv_out[l];
-        SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
-                                                 ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last,
-                                                 q.drop, sd, st));
-        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, ws + L.sum_g, ws + L.sum_gx, g->bn_g[l], g->bn_b[l], st));
-        SED_TRY(sed_bn_relu_pool_drop_bwd_apply(y, ws + L.gradA, ws + L.scale[l], ws + L.shift[l], ws + L.mean[l],
-                                                ws + L.rstd[l], ws + L.sum_g, ws + L.sum_gx, ws + L.dconv[l],
-                                                ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, sd, st));
-        SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], st));
-        return 0;
-    };
+    auto bn_passes = [&](int l, void* st) -> int { return bn_backward(L, c, p, g, x, ws, seed, l, 3, 1.f, st); };
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
@@ -342,6 +390,35 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
+    }
+    return 0;
+}
+
+extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
+                                       const float* x, const float* dlogits, void* workspace, uint64_t seed,
+                                       int phase_begin, int phase_end, float count_scale, void* stream) {
+    SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward_phases: null pointer");
+    SED_REQUIRE(count_scale >= 1.f, "net_backward_phases: count_scale must be >= 1");
+    Layout L;
+    SED_TRY(build_layout(c, 1, &L));
+    SED_REQUIRE(phase_begin >= 0 && phase_end <= 2 * L.n_conv + 1 && phase_begin < phase_end,
+                "net_backward_phases: bad phase range [%d,%d)", phase_begin, phase_end);
+    float* ws = (float*)workspace;
+    const int B = c->B;
+    if (phase_begin == 0) SED_TRY(sed_net_backward(c, p, g, x, dlogits, workspace, seed, 0, 1, stream, nullptr));
+    for (int ph = (phase_begin > 1 ? phase_begin : 1); ph < phase_end; ++ph) {
+        const int k = (ph - 1) >> 1, l = L.n_conv - 1 - k;
+        const ConvL& q = L.cv[l];
+        if (ph & 1) {                                            // 2k+1: reduction pass
+            SED_TRY(bn_backward(L, c, p, g, x, ws, seed, l, 1, 1.f, stream));
+            continue;
+        }
+        SED_TRY(bn_backward(L, c, p, g, x, ws, seed, l, 2, count_scale, stream));
+        if (q.fused) continue;
+        const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
+        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
+        if (l > 0)
+            SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
     }
     return 0;
 }

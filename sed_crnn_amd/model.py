@@ -136,6 +136,7 @@ class HipCRNN(nn.Module):
         self.flat_features = conv_channels[-1] * f
         self.time_factor = math.prod(pt for _, pt in self.pools)
         self.overlap_wgrad = True        # BN backward of block l-1 on an auxiliary stream beside block l's weight gradient
+        self._sync_bn, self._sync_group = False, None
         self._aux_stream = None
         self._ticket = 0
         self._seed_counter = 0
@@ -287,6 +288,26 @@ class HipCRNN(nn.Module):
         self._seed_counter += 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_counter * 0xD1B54A32D192ED03) & _MASK64
 
+    # ── synchronised BatchNorm for data-parallel training ──
+    def enable_sync_bn(self, process_group=None, enabled=True):
+        """Batch statistics (and their backward sums) over ALL ranks' samples: an N-rank run on a sharded global batch
+        then equals the single-device run on that batch (what torch.nn.SyncBatchNorm does for DDP).  Costs one 2C-float
+        all-reduce per conv block in forward and one in backward; the plan runs in phases on one stream."""
+        self._sync_bn, self._sync_group = bool(enabled), process_group
+        return self
+
+    def _sync_world(self):
+        import torch.distributed as dist
+        if self._sync_bn and dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self._sync_group)
+        return 1
+
+    def _allreduce_region(self, cfg, ws, backward, block):
+        import torch.distributed as dist
+        off, n = C.c_size_t(), C.c_size_t()
+        check(lib().sed_net_sync_region(C.byref(cfg), int(backward), block, C.byref(off), C.byref(n)), "sed_net_sync_region")
+        dist.all_reduce(ws[off.value // 4: off.value // 4 + n.value], op=dist.ReduceOp.SUM, group=self._sync_group)
+
     # ── raw plan calls (also used by the fused trainer) ──
     def _run_forward(self, x, training):
         self._check_input(x)
@@ -302,6 +323,16 @@ class HipCRNN(nn.Module):
             self._nbt_pending += 1
             self._last = (cfg, ws)
         seed = self._seed if training else 0
+        world = self._sync_world() if training else 1
+        if world > 1:                                            # phased: all-reduce the statistic sums of every block
+            args = (C.byref(cfg), C.byref(P), _lib.ptr(x), _lib.ptr(logits), _lib.ptr(ws), 1, seed)
+            n = len(self.conv_channels)
+            for l in range(n):
+                check(lib().sed_net_forward_phases(*args, 2 * l, 2 * l + 1, float(world), _lib.stream_ptr()), "sed_net_forward_phases")
+                self._allreduce_region(cfg, ws, 0, l)
+                check(lib().sed_net_forward_phases(*args, 2 * l + 1, 2 * l + 2, float(world), _lib.stream_ptr()), "sed_net_forward_phases")
+            check(lib().sed_net_forward_phases(*args, 2 * n, 2 * n + 1, float(world), _lib.stream_ptr()), "sed_net_forward_phases")
+            return logits
         check(lib().sed_net_forward(C.byref(cfg), C.byref(P), _lib.ptr(x), _lib.ptr(logits), _lib.ptr(ws),
                                     int(training), seed, _lib.stream_ptr()), "sed_net_forward")
         return logits
@@ -311,6 +342,19 @@ class HipCRNN(nn.Module):
         P, G = self._param_structs()
         if stage_end is None:
             stage_end = len(self.conv_channels) + 1
+        world = self._sync_world()
+        if world > 1:                                            # stage s >= 1 = phases 2(s-1)+1 | all-reduce | 2(s-1)+2
+            args = (C.byref(cfg), C.byref(P), C.byref(G), _lib.ptr(x), _lib.ptr(dlogits), _lib.ptr(ws), self._seed)
+            n = len(self.conv_channels)
+            for s in range(stage_begin, stage_end):
+                if s == 0:
+                    check(lib().sed_net_backward_phases(*args, 0, 1, float(world), _lib.stream_ptr()), "sed_net_backward_phases")
+                    continue
+                k = s - 1
+                check(lib().sed_net_backward_phases(*args, 2 * k + 1, 2 * k + 2, float(world), _lib.stream_ptr()), "sed_net_backward_phases")
+                self._allreduce_region(cfg, ws, 1, n - 1 - k)
+                check(lib().sed_net_backward_phases(*args, 2 * k + 2, 2 * k + 3, float(world), _lib.stream_ptr()), "sed_net_backward_phases")
+            return
         if getattr(self, "_aux_stream", None) is None or self._aux_stream.device != x.device:
             self._aux_stream = torch.cuda.Stream(device=x.device)
         aux = C.c_void_p(self._aux_stream.cuda_stream) if self.overlap_wgrad else None

@@ -77,3 +77,57 @@ def test_two_rank_fused_step_equals_manual_gradient_average():
         p.join(30)
     for r in res:
         assert r[1] and r[2] and r[3], r
+
+
+def _worker_syncbn(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    import sed_crnn_amd as sed
+    from oracle import crnn_ref
+    from sed_crnn_amd.dist import broadcast_parameters, shard_batch
+    from sed_crnn_amd.trainer import FusedTrainStep
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(31)
+    kw = dict(conv_channels=32, dropout=0.0, gru_hidden=16)
+    m = sed.TimePooledCRNN(**kw).cuda().enable_sync_bn()
+    broadcast_parameters(m)
+    x, y = crnn_ref.synthetic_batch(8, 1, 40, 32, 4, seed=77)
+    p0 = m.flat_parameters().clone()
+    step = FusedTrainStep(m, lr=1e-3, loss="bce")
+    loss, probs = step.step(shard_batch(x, rank, world).cuda(), shard_batch(y, rank, world).cuda())
+    torch.cuda.synchronize()
+    # single-device run on the WHOLE batch (plain BatchNorm): must be what the synchronised 2-rank run computed
+    ref = sed.TimePooledCRNN(**kw).cuda()
+    ref.flat_parameters().copy_(p0)
+    rstep = FusedTrainStep(ref, lr=1e-3, loss="bce", distributed=False)
+    rloss, rprobs = rstep.step(x.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    per = 8 // world
+    ok_probs = torch.allclose(probs, rprobs[rank * per:(rank + 1) * per], atol=1e-5, rtol=1e-4)
+    ok_grad = torch.allclose(m.flat_grads(), ref.flat_grads(), atol=2e-5, rtol=2e-3)
+    # Adam's first step moves every weight by lr*sign(g): entries whose gradient is rounding noise (the conv biases in
+    # front of BatchNorm, analytically zero) are excluded, everything else must land on the same value
+    sig = ref.flat_grads().abs() > 1e-6
+    ok_param = torch.allclose(m.flat_parameters()[sig], ref.flat_parameters()[sig], atol=2e-5, rtol=1e-3) and int(sig.sum()) > 1000
+    sd, rsd = m.state_dict(), ref.state_dict()
+    ok_running = all(torch.allclose(sd[k], rsd[k], atol=1e-6, rtol=1e-5) for k in sd if "running" in k)
+    q.put((rank, bool(ok_probs), bool(ok_grad), bool(ok_param), bool(ok_running)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sync_bn_equals_single_device_on_the_global_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_syncbn, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in ps:
+        p.join(30)
+    for r in res:
+        assert all(r[1:]), r
