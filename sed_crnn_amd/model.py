@@ -199,6 +199,22 @@ class HipCRNN(nn.Module):
             self._flatten()
         return self
 
+    # ── copy / pickle: ctypes structs, streams and workspaces are per-process; the arenas are rebuilt ──
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("_structs", "_ws", "_aux_stream", "_last", "_arena", "_arena_grad", "_arena_params", "_grad_views",
+                  "_arena_offsets", "_stage_ends"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._structs, self._ws, self._aux_stream, self._arena = None, {}, None, None
+        with torch.no_grad():                      # un-alias the (deep-copied / unpickled) parameters, then re-flatten
+            for p_ in self.parameters():
+                p_.data = p_.data.clone()
+        self._flatten()
+
     def flat_parameters(self):
         return self._arena
 

@@ -143,3 +143,25 @@ def test_mel_basis_and_logmel_oracle_properties():
     peak_hz = 0.5 * (np.argmax(fb[m[4].argmax()]) * 44100 / 2048 + 1000)
     assert abs(peak_hz - 1000) < 120                                   # energy lands in the band around 1 kHz
     assert np.isneginf(logmel_ref.mbe(np.zeros(4096, np.float32))).all()   # log without epsilon (feature.py:59)
+
+
+def test_model_deepcopy_and_pickle_rebuild_the_arena():
+    import copy
+    import io
+    import sed_crnn_amd as sed
+    torch.manual_seed(4)
+    m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0)
+    c = copy.deepcopy(m)
+    assert c.flat_parameters().data_ptr() != m.flat_parameters().data_ptr()
+    assert torch.equal(c.flat_parameters(), m.flat_parameters())
+    with torch.no_grad():
+        c.fc.weight.add_(1.0)                                   # the copy owns its own storage ...
+    assert not torch.equal(c.fc.weight, m.fc.weight)
+    off = [o for p, o in zip(c._arena_params, c._arena_offsets) if p is c.fc.weight][0]
+    assert torch.equal(c.flat_parameters()[off:off + c.fc.weight.numel()].view_as(c.fc.weight), c.fc.weight)   # ... still arena views
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)                     # our own file (not a reference artefact)
+    assert list(r.state_dict().keys()) == list(m.state_dict().keys())
+    assert all(torch.equal(a, b) for a, b in zip(r.state_dict().values(), m.state_dict().values()))
