@@ -10,7 +10,7 @@
 #define GM_LDK 36   // k-contiguous LDS row: 32 + 4 pad floats (16-B slot stride 9) -> conflict-free ds_read_b128
 
 // A_KC / B_KC: operand is contiguous along k (true) or along m/n (false).
-// Block tile (64*WM) x (64*WN), 4 waves as 2x2, each wave WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).
+// Block tile (32*WM*WVM) x (32*WN*WVN), 4 waves as WVM x WVN, each wave WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).
 // LDS tiles are double-buffered: the next K-step's global loads are issued before the MFMA block of the
 // current one and written to the other buffer after it; one barrier per K-step of 32.
 template <bool KC, int NR, int TILE>
@@ -54,19 +54,20 @@ __device__ __forceinline__ void gm_store(const f32x4* reg, float* S, int tid) {
     }
 }
 
-template <int WM, int WN, bool A_KC, bool B_KC>
+template <int WVM, int WVN, int WM, int WN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_k(
     const float* __restrict__ A, long a_si, long a_sk, const float* __restrict__ Bm, long b_sk, long b_sj,
     float* __restrict__ C, long ldc, const float* __restrict__ bias, float beta, int M, int N, int Kfull,
     int a_vec, int b_vec, int k_len, long slab_stride) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    static_assert(WVM * WVN == 4, "four waves per workgroup");
+    constexpr int BM = 32 * WM * WVM, BN = 32 * WN * WVN;
     // split-K: blockIdx.z owns k in [kb, K) and writes its partial product to slab z of C
     const int kb = blockIdx.z * k_len;
     const int K = (kb + k_len < Kfull) ? kb + k_len : Kfull;
     C += (long)blockIdx.z * slab_stride;
     constexpr int A_FLOATS = A_KC ? BM * GM_LDK : GM_BK * BM;
     constexpr int B_FLOATS = B_KC ? BN * GM_LDK : GM_BK * BN;
-    constexpr int NA = 2 * WM, NB = 2 * WN;           // float4 per thread per K-step
+    constexpr int NA = BM / 32, NB = BN / 32;         // float4 per thread per K-step (BM*32 floats / 256 threads / 4)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;                                // [2][A_FLOATS]
     float* Bs0 = smem + 2 * A_FLOATS;                 // [2][B_FLOATS]
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int wm0 = (wave >> 1) * 32 * WM, wn0 = (wave & 1) * 32 * WN;
+    const int wm0 = (wave / WVN) * 32 * WM, wn0 = (wave % WVN) * 32 * WN;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -152,30 +153,30 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
         }
 }
 
-template <int WM, int WN, bool AKC, bool BKC>
+template <int WVM, int WVN, int WM, int WN, bool AKC, bool BKC>
 static int launch_gemm2(dim3 grid, hipStream_t s, const float* A, long a_si, long a_sk, const float* B, long b_sk,
                         long b_sj, float* C, long ldc, const float* bias, float beta, int M, int N, int K, int av, int bv,
                         int k_len, long slab) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 32 * WM * WVM, BN = 32 * WN * WVN;
     constexpr size_t lds = 2 * ((AKC ? BM * GM_LDK : GM_BK * BM) + (BKC ? BN * GM_LDK : GM_BK * BN)) * sizeof(float);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_k<WM, WN, AKC, BKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_k<WVM, WVN, WM, WN, AKC, BKC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { sed_set_error("gemm_f32: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     }
-    gemm_f32_k<WM, WN, AKC, BKC><<<grid, 256, lds, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    gemm_f32_k<WVM, WVN, WM, WN, AKC, BKC><<<grid, 256, lds, s>>>(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
     return 0;
 }
 
-template <int WM, int WN>
+template <int WVM, int WVN, int WM, int WN>
 static int launch_gemm(bool akc, bool bkc, hipStream_t s, const float* A, long a_si, long a_sk,
                        const float* B, long b_sk, long b_sj, float* C, long ldc, const float* bias, float beta,
                        int M, int N, int K, int av, int bv, int splits = 1, int k_len = 0, long slab = 0) {
-    dim3 grid(cdiv(N, 64 * WN), cdiv(M, 64 * WM), splits);
+    dim3 grid(cdiv(N, 32 * WN * WVN), cdiv(M, 32 * WM * WVM), splits);
     if (k_len == 0) k_len = K;
-    if (akc && bkc) return launch_gemm2<WM, WN, true, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
-    if (akc && !bkc) return launch_gemm2<WM, WN, true, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
-    if (!akc && bkc) return launch_gemm2<WM, WN, false, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
-    return launch_gemm2<WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    if (akc && bkc) return launch_gemm2<WVM, WVN, WM, WN, true, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    if (akc && !bkc) return launch_gemm2<WVM, WVN, WM, WN, true, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    if (!akc && bkc) return launch_gemm2<WVM, WVN, WM, WN, false, true>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
+    return launch_gemm2<WVM, WVN, WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
 }
 
 // C[i][j] = sum_z slab[z][i][j] in slab order
@@ -221,7 +222,7 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
     if (splits > 1) {
         SED_REQUIRE(!bias && beta == 0.f, "gemm_f32: split-K path takes no bias / beta");
         int k_len = ((cdiv(K, splits) + GM_BK - 1) / GM_BK) * GM_BK;
-        int rc = launch_gemm<1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, (float*)workspace, N, nullptr, 0.f, M, N, K, av, bv,
+        int rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, (float*)workspace, N, nullptr, 0.f, M, N, K, av, bv,
                                    cdiv(K, k_len), k_len, (long)M * N);
         if (rc) return rc;
         SED_LAUNCH_CHECK("gemm_f32 (split-K)");
@@ -229,14 +230,30 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
         SED_LAUNCH_CHECK("gemm_splitk_reduce");
         return 0;
     }
-    // largest tile that still gives the 256 CUs enough workgroups
-    const long fill = 160;
-    long b22 = (long)cdiv(M, 128) * cdiv(N, 128), b21 = (long)cdiv(M, 128) * cdiv(N, 64), b12 = (long)cdiv(M, 64) * cdiv(N, 128);
+    // tile choice: per-tile efficiency (register / LDS reuse) x how evenly the tiles fill whole rounds of the 256 CUs
+    struct Cand { int bm, bn; double eff; };
+    const Cand cands[5] = {{128, 128, 1.00}, {128, 96, 0.95}, {128, 64, 0.88}, {64, 128, 0.88}, {64, 64, 0.78}};
+    int best = 4;
+    double best_score = -1.0;
+    for (int i = 0; i < 5; ++i) {
+        if (cands[i].bm > 64 && M <= 64) continue;
+        if (cands[i].bn > 64 && N <= 64) continue;
+        long tiles = (long)cdiv(M, cands[i].bm) * cdiv(N, cands[i].bn);
+        double useful = ((double)M * N) / ((double)tiles * cands[i].bm * cands[i].bn);     // edge waste
+        double rounds = (double)((tiles + 255) / 256);
+        double fill = tiles / (rounds * 256.0);
+        if (tiles >= 4 * 256) fill = fill > 0.9 ? fill : 0.9;                              // many rounds: tail matters little
+        double score = cands[i].eff * useful * fill;
+        if (score > best_score) { best_score = score; best = i; }
+    }
     int rc;
-    if (M > 64 && N > 64 && b22 >= fill) rc = launch_gemm<2, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else if (M > 64 && b21 >= fill && (b21 >= b12 || N <= 64)) rc = launch_gemm<2, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else if (N > 64 && b12 >= fill) rc = launch_gemm<1, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
-    else rc = launch_gemm<1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv);
+    switch (best) {
+        case 0: rc = launch_gemm<2, 2, 2, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+        case 1: rc = launch_gemm<4, 1, 1, 3>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+        case 2: rc = launch_gemm<2, 2, 2, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+        case 3: rc = launch_gemm<2, 2, 1, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+        default: rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+    }
     if (rc) return rc;
     SED_LAUNCH_CHECK("gemm_f32");
     return 0;
