@@ -227,6 +227,13 @@ int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_
 size_t sed_col_mean_std_workspace_bytes(int F);
 int sed_col_mean_std(const float* x, long N, int F, float* mean, float* stdv, void* workspace, void* stream);
 
+/* Segment-based metric counts (metrics.py:20-68) of thresholded predictions on the device: pred/lab [rows][K]
+ * (windows concatenated, K <= 32), 1-second blocks of `block` rows.  counts13 (uint64, device):
+ * [0..5] frame-wise TP,Nref,Nsys,S,D,I; [6..8] TP,Nref,Nsys over ceil(rows/block) blocks (F1 keeps the partial block);
+ * [9..12] S,D,I,Nref over floor(rows/block) blocks (ER drops it).  Integer arithmetic: exact. */
+int sed_segment_counts(const float* pred, const float* lab, long rows, int K, int block, float threshold,
+                       unsigned long long* counts13, void* stream);
+
 /* ───────────── whole-network plan (TimePooledCRNN.forward sed.py:105-112 / crnn_lightning.py:66-73) ───────────── */
 typedef struct sed_net_cfg {
     int B, Cin, F, T;                 /* input x [B][Cin][F][T] */

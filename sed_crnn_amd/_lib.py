@@ -91,6 +91,7 @@ SIGNATURES = {
     "sed_pack_sequences": (_i, [_fp, _l, _i, _i, _i, _i, _fp, _stream]),
     "sed_col_mean_std_workspace_bytes": (_sz, [_i]),
     "sed_col_mean_std": (_i, [_fp, _l, _i, _fp, _fp, _fp, _stream]),
+    "sed_segment_counts": (_i, [_fp, _fp, _l, _i, _i, _f, _fp, _stream]),
     "sed_prof_enable": (_i, [C.c_uint]),
     "sed_prof_read": (_i, [_i, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
     "sed_prof_tag_name": (C.c_char_p, [_i]),

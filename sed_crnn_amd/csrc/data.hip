@@ -127,3 +127,52 @@ extern "C" int sed_col_mean_std(const float* x, long N, int F, float* mean, floa
     SED_LAUNCH_CHECK("colstats_final");
     return 0;
 }
+
+// ───────────────────────── segment-based metric counts on the device (metrics.py:20-68) ─────────────────────────
+// One thread per 1-second block of `block` consecutive rows of the concatenated [rows][K] prediction / label
+// matrices (blocks straddle window boundaries exactly like the reference).  Integer counts, so the result is exact and
+// order-independent:  out[0..5]  frame-wise  TP, Nref, Nsys, S, D, I
+//                     out[6..8]  blocks incl. the partial last one (F1: ceil)   TP, Nref, Nsys
+//                     out[9..12] full blocks only (ER: floor)                    S, D, I, Nref
+__global__ void segment_counts_k(const float* __restrict__ pred, const float* __restrict__ lab, long rows, int K, int block,
+                                 float thr, unsigned long long* __restrict__ out) {
+    long bi = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long nceil = (rows + block - 1) / block, nfloor = rows / block;
+    unsigned long long c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (bi < nceil) {
+        long r0 = bi * block, r1 = r0 + block < rows ? r0 + block : rows;
+        unsigned ob = 0, tb = 0;                                   // per-class block maxima as bit masks (K <= 32)
+        for (long r = r0; r < r1; ++r) {
+            unsigned fp = 0, fn = 0;
+            for (int k = 0; k < K; ++k) {
+                bool o = pred[r * K + k] > thr, t = lab[r * K + k] == 1.f;
+                ob |= (unsigned)o << k; tb |= (unsigned)t << k;
+                c[0] += (o && t); c[1] += t; c[2] += o;
+                fp += (o && !t); fn += (t && !o);
+            }
+            c[3] += fp < fn ? fp : fn; c[4] += fn > fp ? fn - fp : 0; c[5] += fp > fn ? fp - fn : 0;
+        }
+        unsigned tp = __popc(ob & tb), nref = __popc(tb), nsys = __popc(ob), fp = __popc(ob & ~tb), fn = __popc(tb & ~ob);
+        c[6] += tp; c[7] += nref; c[8] += nsys;
+        if (bi < nfloor) { c[9] += fp < fn ? fp : fn; c[10] += fn > fp ? fn - fp : 0; c[11] += fp > fn ? fp - fn : 0; c[12] += nref; }
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        unsigned long long v = c[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(out + i, v);
+    }
+}
+
+extern "C" int sed_segment_counts(const float* pred, const float* lab, long rows, int K, int block, float threshold,
+                                  unsigned long long* counts13, void* stream) {
+    SED_REQUIRE(pred && lab && counts13 && rows > 0 && K > 0 && K <= 32 && block > 0, "segment_counts: bad arguments (K <= 32)");
+    hipStream_t s = as_stream(stream);
+    hipError_t e = hipMemsetAsync(counts13, 0, 13 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) { sed_set_error("segment_counts: memset: %s", hipGetErrorString(e)); return (int)e; }
+    long nceil = (rows + block - 1) / block;
+    segment_counts_k<<<cdiv(nceil, 256), 256, 0, s>>>(pred, lab, rows, K, block, threshold, counts13);
+    SED_LAUNCH_CHECK("segment_counts");
+    return 0;
+}

@@ -107,3 +107,33 @@ def test_run_epoch_on_gpu_loader(data):
     assert p.shape == (len(loader) * 16, 8, 1) and t.shape == p.shape and np.isfinite(l0)
     sc = sed.metrics.compute_scores(p > 0.5, t, frames_in_1_sec=5)
     assert set(sc) == {"f1_overall_1sec", "er_overall_1sec"}
+
+
+@pytest.mark.parametrize("N,Tp,K,block", [(6, 8, 1, 5), (5, 7, 6, 4), (33, 8, 1, 5), (2, 3, 2, 50), (16, 32, 1, 5)])
+def test_device_segment_counts_equal_host_metrics(data, N, Tp, K, block):
+    import sed_crnn_amd as sed
+    rng = np.random.default_rng(N * 100 + K)
+    p = rng.random((N, Tp, K)).astype(np.float32)
+    t = (rng.random((N, Tp, K)) > 0.6).astype(np.float32)
+    def same(a, b):                                   # bit-equal, NaN == NaN (fewer rows than one block: ER is 0/0)
+        return a == b or (np.isnan(a) and np.isnan(b))
+    got = sed.metrics.scores_from_counts(sed.metrics.device_counts(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), block).cpu().tolist())
+    with np.errstate(all="ignore"):
+        assert same(got["f1_overall_1sec"], sed.metrics.f1_overall_1sec(p > 0.5, t, block))
+        assert same(got["er_overall_1sec"], sed.metrics.er_overall_1sec(p > 0.5, t, block))
+        assert same(got["f1_overall_framewise"], sed.metrics.f1_overall_framewise(p > 0.5, t))
+        assert same(got["er_overall_framewise"], sed.metrics.er_overall_framewise(p > 0.5, t))
+        d = sed.metrics.compute_scores_device(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), block)
+        h = sed.metrics.compute_scores(p > 0.5, t, block)
+    assert all(same(d[k], h[k]) for k in h)
+
+
+def test_device_counts_golden_and_edges(data):
+    import sed_crnn_amd as sed
+    d = load_golden("g6_metrics.npz")
+    sc = sed.metrics.compute_scores_device(torch.from_numpy(d["p"]).cuda(), torch.from_numpy(d["t"]).cuda(), 5)
+    assert sc["f1_overall_1sec"] == float(d["f1_1s"]) and sc["er_overall_1sec"] == float(d["er_1s"])
+    z, o = torch.zeros(4, 8, 1).cuda(), torch.ones(4, 8, 1).cuda()
+    e = sed.metrics.compute_scores_device(o, z, 5)
+    assert e["f1_overall_1sec"] == 0.0 and np.isinf(e["er_overall_1sec"])
+    assert np.isnan(sed.metrics.compute_scores_device(z, z, 5)["er_overall_1sec"])
