@@ -19,6 +19,8 @@
 #define CV_MTW 5    // max 32-row tiles per wave
 #define WG_NX 6      // wgrad: max float4 per thread of the halo tile   ((TT+2)*(F+2)*8 <= 256*WG_NX)
 #define WG_ND 10     // wgrad: max float4 per thread of the dY tile      (TT*F*32      <= 256*WG_ND)
+#define WG_NX2 8     // wgrad mode 2 (4-row tiles)
+#define WG_ND2 20
 
 #define CV_TPAD 56   // fwd v2: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
 #define CV_NH 8      // fwd v2: max float4 per thread of the halo tile ((TT+2)*(F+2)*8 <= 256*CV_NH)
@@ -534,7 +536,12 @@ struct WgradPlan {
 static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
     WgradPlan p{};
     p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0 && (F % 2 == 0)) ? 1 : 0;
-    if (p.kind == 1) {
+    if (p.kind == 1 && T >= 4 && (6 * (F + 2) * 8) <= 256 * WG_NX2 && 4 * F * 32 <= 256 * WG_ND2 &&
+        ((size_t)6 * (F + 2) * 32 + (size_t)4 * F * 128) * sizeof(float) <= 150 * 1024) {
+        p.TT = 4;                               // mode 2: single LDS buffer, next tile held in registers
+        p.db = 2;
+        p.lds = ((size_t)6 * (F + 2) * 32 + (size_t)4 * F * 128) * sizeof(float);
+    } else if (p.kind == 1) {
         p.TT = 2;
         if (p.TT > T) p.TT = T;
         p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
@@ -651,7 +658,10 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* _
 // D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions.
 // DB=true: both LDS tiles are double-buffered and the next tile's global loads are issued before the
 // MFMA loop of the current one (register prefetch, NX+ND float4 per thread), one barrier per tile.
-template <bool DB>
+// MODE 0: plain staging (any shape that fits LDS)   1: double-buffered 2-row tiles   2: single-buffered 4-row tiles with
+// the whole next tile prefetched into registers (staging cost amortised over twice the MFMA work; ablation: staging was
+// 12 % of the kernel at 2-row tiles)
+template <int MODE>
 __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
     int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
@@ -659,6 +669,8 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     const int F2 = F + 2;
     const int HR = (TT + 2) * F2;
     const int MROWS = TT * F;
+    constexpr bool DB = MODE != 0;
+    constexpr int NX = MODE == 2 ? WG_NX2 : WG_NX, ND = MODE == 2 ? WG_ND2 : WG_ND;
     const int XH = HR * 32, DYS = MROWS * 128, BUF = XH + DYS;
     const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -671,14 +683,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-    f32x4 px[DB ? WG_NX : 1], pd[DB ? WG_ND : 1];
+    f32x4 px[DB ? NX : 1], pd[DB ? ND : 1];
     // tile-invariant part of the staging addresses, computed once per block: element offset from the tile origin
     // (b, t0, f = 0) and the time row it belongs to (-1: padding or out of the tile); per tile only a base pointer,
     // one add and one range test per float4 remain (the index math otherwise runs with the MFMA pipe idle)
-    int xo[DB ? WG_NX : 1], xt[DB ? WG_NX : 1], dofs[DB ? WG_ND : 1], dt[DB ? WG_ND : 1];
+    int xo[DB ? NX : 1], xt[DB ? NX : 1], dofs[DB ? ND : 1], dt[DB ? ND : 1];
     if (DB) {
 #pragma unroll
-        for (int u = 0; u < WG_NX; ++u) {
+        for (int u = 0; u < NX; ++u) {
             int i = tid + u * 256, row = i >> 3, q = i & 7;
             int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
             bool ok = i < HR * 8 && ff >= 1 && ff <= F;
@@ -686,7 +698,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
             xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
         }
 #pragma unroll
-        for (int u = 0; u < WG_ND; ++u) {
+        for (int u = 0; u < ND; ++u) {
             int i = tid + u * 256, row = i >> 5, q = i & 31;
             int tl = sed_fdiv(row, invF);
             dt[u] = (i < MROWS * 32) ? tl : (1 << 20);
@@ -698,14 +710,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         const float* xb = x + ((size_t)b * T + t0) * F * Cin;
         const float* db = dy + ((size_t)b * T + t0) * F * Cout;
 #pragma unroll
-        for (int u = 0; u < WG_NX; ++u) {
+        for (int u = 0; u < NX; ++u) {
             f32x4 v = {0, 0, 0, 0};
             int t = t0 + xt[u];
             if (t >= 0 && t < T) v = *(const f32x4*)(xb + xo[u]);
             px[u] = v;
         }
 #pragma unroll
-        for (int u = 0; u < WG_ND; ++u) {
+        for (int u = 0; u < ND; ++u) {
             f32x4 v = {0, 0, 0, 0};
             if (t0 + dt[u] < T) v = *(const f32x4*)(db + dofs[u]);
             pd[u] = v;
@@ -713,12 +725,12 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     };
     auto commit = [&](float* buf) {       // registers -> LDS
 #pragma unroll
-        for (int u = 0; u < WG_NX; ++u) {
+        for (int u = 0; u < NX; ++u) {
             int i = tid + u * 256;
             if (i < HR * 8) *(f32x4*)(buf + i * 4) = px[u];
         }
 #pragma unroll
-        for (int u = 0; u < WG_ND; ++u) {
+        for (int u = 0; u < ND; ++u) {
             int i = tid + u * 256;
             if (i < MROWS * 32) *(f32x4*)(buf + XH + i * 4) = pd[u];
         }
@@ -758,7 +770,19 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         }
     };
 
-    if (DB) {
+    if (MODE == 2) {
+        int tile = blockIdx.x;
+        if (tile < ntiles) { fetch(tile); commit(smem); }
+        __syncthreads();
+        for (; tile < ntiles; tile += gridDim.x) {
+            const int nxt = tile + gridDim.x;
+            if (nxt < ntiles) fetch(nxt);
+            compute(smem);
+            __syncthreads();                       // every wave is done reading the tile
+            if (nxt < ntiles) commit(smem);
+            __syncthreads();
+        }
+    } else if (MODE == 1) {
         int tile = blockIdx.x, cur = 0;
         if (tile < ntiles) { fetch(tile); commit(smem); }
         __syncthreads();
@@ -830,12 +854,15 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
                       p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
     if (p.kind == 1) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
-        if (p.db) {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
-            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        if (p.db == 2) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<2>, p.lds));
+            conv3x3_mfma_wgrad_k<2><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else if (p.db == 1) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<1>, p.lds));
+            conv3x3_mfma_wgrad_k<1><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
         } else {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
-            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<0>, p.lds));
+            conv3x3_mfma_wgrad_k<0><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
         }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
