@@ -95,7 +95,9 @@ int sed_bn_finalize_eval(const float* gamma, const float* beta, const float* run
  * (seed, logical element index) so the backward pass regenerates it. */
 int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* shift, float* out,
                               int B, int T, int F, int C, int pool_f, int pool_t, int out_tcf,
-                              float drop_p, uint64_t seed, void* stream);
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
+/* seed_dev (here and below; may be NULL): device pointer to a per-step salt added to `seed`, so that a captured
+ * hipGraph of the step draws fresh masks on every replay (see sed_step_advance). */
 
 /* Backward of the block above (training statistics).  Two passes:
  *  reduce: partials [rows][2][C] of  sum g  and  sum g*xhat  where g is dout routed through
@@ -106,14 +108,14 @@ int sed_bn_bwd_rows(int B, int T, int pool_t);   /* partial rows written by the 
 int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const float* scale,
                                      const float* shift, const float* mean, const float* rstd,
                                      float* partials, int B, int T, int F, int C, int pool_f,
-                                     int pool_t, int out_tcf, float drop_p, uint64_t seed, void* stream);
+                                     int pool_t, int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
                         float* dgamma, float* dbeta, void* stream);
 int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const float* scale,
                                     const float* shift, const float* mean, const float* rstd,
                                     const float* sum_g, const float* sum_gx, float* dy,
                                     float* dbias_partials, int B, int T, int F, int C, int pool_f,
-                                    int pool_t, int out_tcf, float drop_p, uint64_t seed, void* stream);
+                                    int pool_t, int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* out[c] = sum_r partials[r][c] in row order (double accumulation). */
 int sed_reduce_rows(const float* partials, int rows, int C, int row_stride, float* out, void* stream);
 
@@ -129,18 +131,18 @@ int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* s
                     int B, int Cin, int F, int T, int C, void* stream);
 int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
                                     const float* shift, float* out, int B, int Cin, int F, int T, int C,
-                                    int pool_f, int pool_t, float drop_p, uint64_t seed, void* stream);
+                                    int pool_f, int pool_t, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
                          const float* scale, const float* shift, const float* mean, const float* rstd,
                          float* partials, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
-                         float drop_p, uint64_t seed, void* stream);
+                         float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 size_t sed_conv1_bwd_apply_workspace_bytes(int B, int Cin, int T, int C);
 /* dy is formed on the fly: writes dw_oihw [C][Cin][3][3] and the conv-bias gradient only. */
 int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias, const float* dout,
                               const float* scale, const float* shift, const float* mean, const float* rstd,
                               const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                               void* workspace, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
-                              float drop_p, uint64_t seed, void* stream);
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 
 /* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
  * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.
@@ -201,7 +203,11 @@ int sed_grad_norm_clip_coef(const float* g, long n, float max_norm, float* norm_
  * (device pointer, may be NULL = 1) first.  step >= 1. */
 int sed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* grad_scale,
-                  void* stream);
+                  const uint64_t* step_state, void* stream);
+/* step_state (may be NULL): device pointer to {dropout salt, optimiser step}; when given, the step count is read from
+ * step_state[1] on the device instead of `step`.  sed_step_advance increments both words (one tiny launch per fit
+ * step): with it the whole fit step is a replayable hipGraph. */
+int sed_step_advance(uint64_t* step_state, void* stream);
 
 /* ───────────── log-mel front end (feature.py:55-59 via librosa.stft / filters.mel) ─────────────
  * pcm [n_samples] mono f32 -> out [n_frames][n_mels] = log(mel @ |STFT|^2), n_frames = 1 + n_samples/hop.
@@ -269,7 +275,7 @@ size_t sed_net_workspace_bytes(const sed_net_cfg* cfg, int training);
 /* logits [B][T'][D_last].  training=1: batch statistics, dropout, activations kept in `workspace`
  * for sed_net_backward; running stats updated in place. */
 int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float* x, float* logits,
-                    void* workspace, int training, uint64_t seed, void* stream);
+                    void* workspace, int training, uint64_t seed, const uint64_t* seed_dev, void* stream);
 /* Gradients of every parameter into `g` (same layouts as `p`; written, not accumulated).
  * Stages let the host overlap the gradient all-reduce with the rest of backward:
  *   stage 0 = dense head + GRU stack, stage s>=1 = conv block l = n_conv - s.  Run stages
@@ -281,7 +287,7 @@ int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float
  * MFMA-bound weight gradient on `stream`; the stage of block l-1 starts by waiting for it (hipEvents).  Stages must
  * therefore be run in order with the same aux_stream for the whole backward. */
 int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
-                     const float* x, const float* dlogits, void* workspace, uint64_t seed,
+                     const float* x, const float* dlogits, void* workspace, uint64_t seed, const uint64_t* seed_dev,
                      int stage_begin, int stage_end, void* stream, void* aux_stream);
 
 /* Phased execution, for synchronised BatchNorm in data-parallel training: the per-block statistics

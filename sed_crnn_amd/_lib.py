@@ -56,19 +56,19 @@ SIGNATURES = {
     "sed_conv1_fused_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sed_conv1_fused_rows": (_i, [_i, _i]),
     "sed_conv1_stats": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
-    "sed_conv1_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
-    "sed_conv1_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_conv1_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
+    "sed_conv1_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_conv1_bwd_apply_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_bn_finalize_train": (_i, [_fp, _i, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
     "sed_bn_stat_sums": (_i, [_fp, _i, _i, _fp, _stream]),
     "sed_bn_finalize_from_sums": (_i, [_fp, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
     "sed_bn_finalize_eval": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _stream]),
-    "sed_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_bn_bwd_rows": (_i, [_i, _i, _i]),
-    "sed_bn_relu_pool_drop_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_bn_relu_pool_drop_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_bn_bwd_finalize": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _stream]),
-    "sed_bn_relu_pool_drop_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _stream]),
+    "sed_bn_relu_pool_drop_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_reduce_rows": (_i, [_fp, _i, _i, _i, _fp, _stream]),
     "sed_gemm_f32": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _fp, _f, _i, _i, _i, _stream]),
     "sed_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -85,7 +85,8 @@ SIGNATURES = {
     "sed_scale": (_i, [_fp, _l, _f, _stream]),
     "sed_sqnorm_workspace_bytes": (_sz, [_l]),
     "sed_grad_norm_clip_coef": (_i, [_fp, _l, _f, _fp, _fp, _stream]),
-    "sed_adam_step": (_i, [_fp, _fp, _fp, _fp, _l, _f, _f, _f, _f, _f, _i, _fp, _stream]),
+    "sed_adam_step": (_i, [_fp, _fp, _fp, _fp, _l, _f, _f, _f, _f, _f, _i, _fp, _fp, _stream]),
+    "sed_step_advance": (_i, [_fp, _stream]),
     "sed_logmel": (_i, [_fp, _l, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
     "sed_window_batch": (_i, [_fp, _fp, _l, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _stream]),
     "sed_pack_sequences": (_i, [_fp, _l, _i, _i, _i, _i, _fp, _stream]),
@@ -97,11 +98,11 @@ SIGNATURES = {
     "sed_prof_tag_name": (C.c_char_p, [_i]),
     "sed_net_out_shape": (_i, [C.POINTER(NetCfg), C.POINTER(_i), C.POINTER(_i)]),
     "sed_net_workspace_bytes": (_sz, [C.POINTER(NetCfg), _i]),
-    "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _stream]),
+    "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _fp, _stream]),
     "sed_net_sync_region": (_i, [C.POINTER(NetCfg), _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "sed_net_forward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _i, _i, _f, _stream]),
     "sed_net_backward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _f, _stream]),
-    "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _stream, _stream]),
+    "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _fp, _i, _i, _stream, _stream]),
 }
 
 _lib = None

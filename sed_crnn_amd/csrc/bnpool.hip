@@ -189,7 +189,9 @@ extern "C" int sed_reduce_rows(const float* part, int rows, int C, int row_strid
 // channels-last output: one thread per output float4.
 __global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_k(
     const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed,
+    const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;   // per-step salt kept on the device (graph replay)
     const int Tp = T / pt, Fp = F / pf, C4 = C >> 2;
     const size_t n = (size_t)B * Tp * Fp * C4;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -220,7 +222,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_k(
 // GRU-order output [B][Tp][C][Fp]: one block per (b,tp) row group, LDS transpose.
 __global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_tcf_k(
     const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    float* __restrict__ out, int B, int T, int F, int C, int pf, int pt, float drop_p, uint64_t seed,
+    const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;   // per-step salt kept on the device (graph replay)
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [Fp][C+1]
     const int Tp = T / pt, Fp = F / pf, C4 = C >> 2, LD = C + 1;
     const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -265,7 +269,7 @@ static int check_pool(const char* who, int B, int T, int F, int C, int pf, int p
 
 extern "C" int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* shift, float* out, int B,
                                          int T, int F, int C, int pf, int pt, int out_tcf, float drop_p,
-                                         uint64_t seed, void* stream) {
+                                         uint64_t seed, const uint64_t* seed_dev, void* stream) {
     SED_REQUIRE(y && scale && shift && out, "bn_relu_pool_drop_fwd: null pointer");
     SED_TRY(check_pool("bn_relu_pool_drop_fwd", B, T, F, C, pf, pt));
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_relu_pool_drop_fwd: drop_p=%f out of [0,1)", drop_p);
@@ -275,13 +279,13 @@ extern "C" int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, con
     if (!out_tcf) {
         size_t n = (size_t)B * Tp * Fp * (C / 4);
         int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-        bn_relu_pool_drop_fwd_k<<<grid, 256, 0, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed);
+        bn_relu_pool_drop_fwd_k<<<grid, 256, 0, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed, seed_dev);
     } else {
         size_t lds = (size_t)Fp * (C + 1) * sizeof(float);
         SED_REQUIRE(lds <= 150 * 1024, "bn_relu_pool_drop_fwd: F'*C tile too large for LDS");
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_fwd_tcf_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int grid = B * Tp < 4096 ? B * Tp : 4096;
-        bn_relu_pool_drop_fwd_tcf_k<<<grid, 256, lds, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed);
+        bn_relu_pool_drop_fwd_tcf_k<<<grid, 256, lds, s>>>(y, scale, shift, out, B, T, F, C, pf, pt, drop_p, seed, seed_dev);
     }
     SED_LAUNCH_CHECK("bn_relu_pool_drop_fwd");
     return 0;
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float* __restrict__ dy,
     float* __restrict__ partials, int B, int T, int F, int C, int pf, int pt, int out_tcf, float drop_p,
-    uint64_t seed) {
+    uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;   // per-step salt kept on the device (graph replay)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Tp = T / pt, Fp = F / pf, C4 = C >> 2, LD = C + 1;
     float* tile = smem;                                   // [Fp][C+1] (tcf only)
@@ -415,7 +420,8 @@ static size_t bwd_lds(int F, int C, int pf, int out_tcf) {
 extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const float* scale,
                                                 const float* shift, const float* mean, const float* rstd,
                                                 float* partials, int B, int T, int F, int C, int pf, int pt,
-                                                int out_tcf, float drop_p, uint64_t seed, void* stream) {
+                                                int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                                void* stream) {
     SED_REQUIRE(y && dout && scale && shift && mean && rstd && partials, "bn_bwd_reduce: null pointer");
     SED_TRY(check_pool("bn_bwd_reduce", B, T, F, C, pf, pt));
     SED_REQUIRE(C / 4 <= 256, "bn_bwd_reduce: C=%d too large (max 1024)", C);
@@ -425,7 +431,7 @@ extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dou
     int grid = sed_bn_bwd_rows(B, T, pt);
     SedProfScope prof(SED_K_BN_BWD_REDUCE, as_stream(stream), 4.0 * B * C * ((double)T * F + (double)(T / pt) * (F / pf)));
     bn_relu_pool_drop_bwd_k<0><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, nullptr, nullptr,
-                                                                       nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed);
+                                                                       nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
     SED_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
@@ -466,7 +472,8 @@ extern "C" int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout
                                                const float* shift, const float* mean, const float* rstd,
                                                const float* sum_g, const float* sum_gx, float* dy,
                                                float* dbias_partials, int B, int T, int F, int C, int pf, int pt,
-                                               int out_tcf, float drop_p, uint64_t seed, void* stream) {
+                                               int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                               void* stream) {
     SED_REQUIRE(y && dout && scale && shift && mean && rstd && sum_g && sum_gx && dy && dbias_partials,
                 "bn_bwd_apply: null pointer");
     SED_TRY(check_pool("bn_bwd_apply", B, T, F, C, pf, pt));
@@ -477,7 +484,7 @@ extern "C" int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout
     int grid = sed_bn_bwd_rows(B, T, pt);
     SedProfScope prof(SED_K_BN_BWD_APPLY, as_stream(stream), 4.0 * B * C * (2.0 * T * F + (double)(T / pt) * (F / pf)));
     bn_relu_pool_drop_bwd_k<1><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, sum_g, sum_gx, dy,
-                                                                       dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed);
+                                                                       dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
     SED_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
 }

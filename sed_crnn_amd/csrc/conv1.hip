@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
     const float* __restrict__ dout, float* __restrict__ out, float* __restrict__ partials,
-    int B, int F, int T, int C, int pf, int pt, float drop_p, uint64_t seed) {
+    int B, int F, int T, int C, int pf, int pt, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;   // per-step salt kept on the device (graph replay)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = F + 2;
     float* halo = smem;                                       // [(TT+2)][F2][CIN]
@@ -249,15 +250,15 @@ template <int MODE>
 static int c1_launch(const float* x, const float* wp, const float* bias, const float* scale, const float* shift,
                      const float* mean, const float* rstd, const float* sum_g, const float* sum_gx, const float* dout,
                      float* out, float* partials, int B, int Cin, int F, int T, int C, int pf, int pt, float drop_p,
-                     uint64_t seed, hipStream_t s) {
+                     uint64_t seed, const uint64_t* seed_dev, hipStream_t s) {
     size_t lds = c1_lds(Cin, F, C, MODE);
     int grid = sed_conv1_fused_rows(B, T);
     if (Cin == 1) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_fused_k<1, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed);
+        conv1_fused_k<1, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);
     } else {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_fused_k<2, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed);
+        conv1_fused_k<2, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);
     }
     return 0;
 }
@@ -273,20 +274,21 @@ extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bia
     C1_CHECK("conv1_stats");
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_CONV_SMALL_FWD, s, 4.0 * B * Cin * (double)F * T);
-    c1_launch<0>(x, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partials, B, Cin, F, T, C, 1, 1, 0.f, 0, s);
+    c1_launch<0>(x, wp, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stat_partials, B, Cin, F, T, C, 1, 1, 0.f, 0, nullptr, s);
     SED_LAUNCH_CHECK("conv1_stats");
     return 0;
 }
 
 extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
                                                const float* shift, float* out, int B, int Cin, int F, int T, int C,
-                                               int pf, int pt, float drop_p, uint64_t seed, void* stream) {
+                                               int pf, int pt, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                               void* stream) {
     SED_REQUIRE(x && wp && scale && shift && out, "conv1_fwd: null pointer");
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_fwd: drop_p=%f out of [0,1)", drop_p);
     C1_CHECK("conv1_fwd");
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_FWD, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
-    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_fwd");
     return 0;
 }
@@ -294,12 +296,12 @@ extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, 
 extern "C" int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
                                     const float* scale, const float* shift, const float* mean, const float* rstd,
                                     float* partials, int B, int Cin, int F, int T, int C, int pf, int pt, float drop_p,
-                                    uint64_t seed, void* stream) {
+                                    uint64_t seed, const uint64_t* seed_dev, void* stream) {
     SED_REQUIRE(x && wp && dout && scale && shift && mean && rstd && partials, "conv1_bwd_reduce: null pointer");
     C1_CHECK("conv1_bwd_reduce");
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_BWD_REDUCE, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
-    c1_launch<2>(x, wp, bias, scale, shift, mean, rstd, nullptr, nullptr, dout, nullptr, partials, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    c1_launch<2>(x, wp, bias, scale, shift, mean, rstd, nullptr, nullptr, dout, nullptr, partials, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_bwd_reduce");
     return 0;
 }
@@ -312,13 +314,13 @@ extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const 
                                          const float* scale, const float* shift, const float* mean, const float* rstd,
                                          const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                                          void* workspace, int B, int Cin, int F, int T, int C, int pf, int pt,
-                                         float drop_p, uint64_t seed, void* stream) {
+                                         float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
     SED_REQUIRE(x && wp && dout && scale && shift && mean && rstd && sum_g && sum_gx && dw_oihw && dbias && workspace,
                 "conv1_bwd_apply_wgrad: null pointer");
     C1_CHECK("conv1_bwd_apply_wgrad");
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_BWD_APPLY, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
-    c1_launch<3>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, nullptr, (float*)workspace, B, Cin, F, T, C, pf, pt, drop_p, seed, s);
+    c1_launch<3>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, nullptr, (float*)workspace, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_bwd_apply_wgrad");
     int rows = sed_conv1_fused_rows(B, T), n = (1 + 9 * Cin) * C;
     conv1_wgrad_reduce_k<<<cdiv(n, 32), 1024, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias);

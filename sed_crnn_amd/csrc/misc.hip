@@ -131,7 +131,13 @@ extern "C" int sed_grad_norm_clip_coef(const float* g, long n, float max_norm, f
 // ───────────────────────── Adam (coupled L2 weight decay) ─────────────────────────
 __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                              float wd, float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
+                                              float wd, float bc1, float bc2_sqrt, const float* __restrict__ gscale,
+                                              const uint64_t* __restrict__ step_dev) {
+    if (step_dev) {                       // optimiser step kept on the device (graph replay): bias corrections in-kernel
+        const double t = (double)step_dev[1];
+        bc1 = (float)(1.0 - pow((double)b1, t));
+        bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+    }
     const float gs = gscale ? gscale[0] : 1.f;
     const float step = lr / bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -147,15 +153,28 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
 }
 
 extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, const float* grad_scale, void* stream) {
-    SED_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+                             float eps, float weight_decay, int step, const float* grad_scale, const uint64_t* step_state,
+                             void* stream) {
+    SED_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_state), "adam_step: bad arguments");
+    if (step < 1) step = 1;
     double bc1 = 1.0 - pow((double)beta1, (double)step);
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     int nb = (int)((n + 255) / 256);
     if (nb > 4096) nb = 4096;
     SedProfScope prof(SED_K_ADAM, as_stream(stream), 28.0 * n);
     adam_k<<<nb, 256, 0, as_stream(stream)>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                                              (float)sqrt(bc2), grad_scale);
+                                              (float)sqrt(bc2), grad_scale, step_state);
     SED_LAUNCH_CHECK("adam_step");
+    return 0;
+}
+
+// device-resident step state {dropout salt, optimiser step}: advanced once per fit step by this one-thread kernel so that a
+// captured hipGraph of the step draws fresh dropout masks and uses the right Adam bias correction on every replay
+__global__ void step_advance_k(uint64_t* st) { st[0] += 1; st[1] += 1; }
+
+extern "C" int sed_step_advance(uint64_t* state2, void* stream) {
+    SED_REQUIRE(state2, "step_advance: null pointer");
+    step_advance_k<<<1, 1, 0, as_stream(stream)>>>(state2);
+    SED_LAUNCH_CHECK("step_advance");
     return 0;
 }

@@ -157,7 +157,7 @@ extern "C" size_t sed_net_workspace_bytes(const sed_net_cfg* cfg, int training) 
 
 // phases [pb, pe): 2l = conv block l (+ statistic sums), 2l+1 = finalise + normalise/pool, 2*n_conv = GRU + head
 static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits, void* workspace,
-                        int training, uint64_t seed, int pb, int pe, float count_scale, void* stream) {
+                        int training, uint64_t seed, const uint64_t* seed_dev, int pb, int pe, float count_scale, void* stream) {
     SED_REQUIRE(p && x && logits && workspace, "net_forward: null pointer");
     Layout L;
     SED_TRY(build_layout(c, training, &L));
@@ -200,11 +200,11 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         if (q.fused)
             SED_TRY(sed_conv1_bn_relu_pool_drop_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.scale[l], ws + L.shift[l],
                                                     ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
-                                                    training ? q.drop : 0.f, layer_seed(seed, l), stream));
+                                                    training ? q.drop : 0.f, layer_seed(seed, l), seed_dev, stream));
         else
             SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
                                               q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
-                                              layer_seed(seed, l), stream));
+                                              layer_seed(seed, l), seed_dev, stream));
     }
     if (pe <= 2 * L.n_conv) return 0;
     const int M = L.M;
@@ -241,15 +241,15 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
 }
 
 extern "C" int sed_net_forward(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
-                               void* workspace, int training, uint64_t seed, void* stream) {
-    return forward_impl(c, p, x, logits, workspace, training, seed, 0, 2 * (c ? c->n_conv : 0) + 1, 1.f, stream);
+                               void* workspace, int training, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+    return forward_impl(c, p, x, logits, workspace, training, seed, seed_dev, 0, 2 * (c ? c->n_conv : 0) + 1, 1.f, stream);
 }
 
 extern "C" int sed_net_forward_phases(const sed_net_cfg* c, const sed_net_params* p, const float* x, float* logits,
                                       void* workspace, int training, uint64_t seed, int phase_begin, int phase_end,
                                       float count_scale, void* stream) {
     SED_REQUIRE(count_scale >= 1.f, "net_forward_phases: count_scale must be >= 1");
-    return forward_impl(c, p, x, logits, workspace, training, seed, phase_begin, phase_end, count_scale, stream);
+    return forward_impl(c, p, x, logits, workspace, training, seed, nullptr, phase_begin, phase_end, count_scale, stream);
 }
 
 extern "C" int sed_net_sync_region(const sed_net_cfg* c, int backward, int block, size_t* offset_bytes, size_t* n_floats) {
@@ -265,7 +265,7 @@ extern "C" int sed_net_sync_region(const sed_net_cfg* c, int backward, int block
 // part 1 = reduction pass (sum g, sum g*xhat -> ws.sum_g[0..2C), dgamma, dbeta), part 2 = apply pass (dconv[l] + conv-bias
 // gradient; fused block: + weight gradient), 3 = both.  count_scale > 1: the sums were all-reduced over that many ranks.
 static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
-                       const float* x, float* ws, uint64_t seed, int l, int part, float count_scale, void* st) {
+                       const float* x, float* ws, uint64_t seed, const uint64_t* seed_dev, int l, int part, float count_scale, void* st) {
     const ConvL& q = L.cv[l];
     const int B = c->B, last = (l == L.n_conv - 1);
     const uint64_t sd = layer_seed(seed, l);
@@ -276,11 +276,11 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
         if (q.fused)
             SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                          ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
-                                         q.drop, sd, st));
+                                         q.drop, sd, seed_dev, st));
         else
             SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                                      ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf,
-                                                     q.pt, last, q.drop, sd, st));
+                                                     q.pt, last, q.drop, sd, seed_dev, st));
         SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.bn_rows, q.C, sum_g, sum_gx, g->bn_g[l], g->bn_b[l], st));
     }
     if (part & 2) {
@@ -288,11 +288,11 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
         if (q.fused) {
             SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                               ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
-                                              ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, st));
+                                              ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, seed_dev, st));
         } else {
             SED_TRY(sed_bn_relu_pool_drop_bwd_apply(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                                     ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, ws + L.dconv[l],
-                                                    ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, sd, st));
+                                                    ws + L.dbias_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, sd, seed_dev, st));
             SED_TRY(sed_reduce_rows(ws + L.dbias_part, q.bn_rows, q.C, q.C, g->conv_b[l], st));
         }
     }
@@ -301,7 +301,7 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
 
 extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
                                 const float* x, const float* dlogits, void* workspace, uint64_t seed,
-                                int stage_begin, int stage_end, void* stream, void* aux_stream) {
+                                const uint64_t* seed_dev, int stage_begin, int stage_end, void* stream, void* aux_stream) {
     SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward: null pointer");
     // cross-stream ordering (host objects, created once): ev_dg[l] = data gradient of block l complete (main stream),
     // ev_bn[l] = BatchNorm backward of block l complete (auxiliary stream)
@@ -370,7 +370,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
     }
     // ── conv blocks, last to first ──
-    auto bn_passes = [&](int l, void* st) -> int { return bn_backward(L, c, p, g, x, ws, seed, l, 3, 1.f, st); };
+    auto bn_passes = [&](int l, void* st) -> int { return bn_backward(L, c, p, g, x, ws, seed, seed_dev, l, 3, 1.f, st); };
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
@@ -405,15 +405,15 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
                 "net_backward_phases: bad phase range [%d,%d)", phase_begin, phase_end);
     float* ws = (float*)workspace;
     const int B = c->B;
-    if (phase_begin == 0) SED_TRY(sed_net_backward(c, p, g, x, dlogits, workspace, seed, 0, 1, stream, nullptr));
+    if (phase_begin == 0) SED_TRY(sed_net_backward(c, p, g, x, dlogits, workspace, seed, nullptr, 0, 1, stream, nullptr));
     for (int ph = (phase_begin > 1 ? phase_begin : 1); ph < phase_end; ++ph) {
         const int k = (ph - 1) >> 1, l = L.n_conv - 1 - k;
         const ConvL& q = L.cv[l];
         if (ph & 1) {                                            // 2k+1: reduction pass
-            SED_TRY(bn_backward(L, c, p, g, x, ws, seed, l, 1, 1.f, stream));
+            SED_TRY(bn_backward(L, c, p, g, x, ws, seed, nullptr, l, 1, 1.f, stream));
             continue;
         }
-        SED_TRY(bn_backward(L, c, p, g, x, ws, seed, l, 2, count_scale, stream));
+        SED_TRY(bn_backward(L, c, p, g, x, ws, seed, nullptr, l, 2, count_scale, stream));
         if (q.fused) continue;
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));

@@ -300,6 +300,10 @@ class HipCRNN(nn.Module):
         if x.shape[3] % self.time_factor:
             raise ValueError(f"T={x.shape[3]} must be a multiple of {self.time_factor}")
 
+    def _graph_seed(self):
+        # constant base seed of a captured step; the per-step variation comes from the device-side salt
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x51ED270B) & _MASK64
+
     def _next_seed(self):
         self._seed_counter += 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_counter * 0xD1B54A32D192ED03) & _MASK64
@@ -325,7 +329,9 @@ class HipCRNN(nn.Module):
         dist.all_reduce(ws[off.value // 4: off.value // 4 + n.value], op=dist.ReduceOp.SUM, group=self._sync_group)
 
     # ── raw plan calls (also used by the fused trainer) ──
-    def _run_forward(self, x, training):
+    def _run_forward(self, x, training, step_state=None):
+        """step_state: optional device tensor {dropout salt, optimiser step} (uint64[2]) read by the kernels instead of a
+        host-side seed, which makes the launch sequence replayable as a hipGraph (trainer.FusedTrainStep(graph=True))."""
         self._check_input(x)
         x = x.contiguous().float()
         B, _, _, T = x.shape
@@ -335,9 +341,10 @@ class HipCRNN(nn.Module):
         logits = torch.empty(B, T // self.time_factor, self.dense[-1], device=x.device, dtype=torch.float32)
         if training:
             self._ticket += 1
-            self._seed = self._next_seed()
+            self._seed = self._next_seed() if step_state is None else self._graph_seed()
             self._nbt_pending += 1
             self._last = (cfg, ws)
+            self._last_state = step_state
         seed = self._seed if training else 0
         world = self._sync_world() if training else 1
         if world > 1:                                            # phased: all-reduce the statistic sums of every block
@@ -350,7 +357,8 @@ class HipCRNN(nn.Module):
             check(lib().sed_net_forward_phases(*args, 2 * n, 2 * n + 1, float(world), _lib.stream_ptr()), "sed_net_forward_phases")
             return logits
         check(lib().sed_net_forward(C.byref(cfg), C.byref(P), _lib.ptr(x), _lib.ptr(logits), _lib.ptr(ws),
-                                    int(training), seed, _lib.stream_ptr()), "sed_net_forward")
+                                    int(training), seed, _lib.ptr(step_state) if training else None, _lib.stream_ptr()),
+              "sed_net_forward")
         return logits
 
     def _run_backward(self, x, dlogits, stage_begin=0, stage_end=None):
@@ -375,8 +383,8 @@ class HipCRNN(nn.Module):
             self._aux_stream = torch.cuda.Stream(device=x.device)
         aux = C.c_void_p(self._aux_stream.cuda_stream) if self.overlap_wgrad else None
         check(lib().sed_net_backward(C.byref(cfg), C.byref(P), C.byref(G), _lib.ptr(x), _lib.ptr(dlogits),
-                                     _lib.ptr(ws), self._seed, stage_begin, stage_end, _lib.stream_ptr(), aux),
-              "sed_net_backward")
+                                     _lib.ptr(ws), self._seed, _lib.ptr(getattr(self, "_last_state", None)), stage_begin,
+                                     stage_end, _lib.stream_ptr(), aux), "sed_net_backward")
 
     # ── nn.Module surface ──
     def forward(self, x):                                   # x [B,Cin,F,T] -> logits [B,T',K]

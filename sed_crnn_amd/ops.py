@@ -77,7 +77,7 @@ def bn_relu_pool_drop_fwd(y, scale, shift, pool_f, pool_t, out_tcf=False, drop_p
     Tp, Fp = T // pool_t, F // pool_f
     out = torch.empty((B, Tp, Cc, Fp) if out_tcf else (B, Tp, Fp, Cc), device=y.device)
     check(lib().sed_bn_relu_pool_drop_fwd(ptr(_f32c(y)), ptr(scale), ptr(shift), ptr(out), B, T, F, Cc, pool_f, pool_t,
-                                          int(out_tcf), drop_p, seed, stream_ptr()), "bn_relu_pool_drop_fwd")
+                                          int(out_tcf), drop_p, seed, None, stream_ptr()), "bn_relu_pool_drop_fwd")
     return out
 
 
@@ -88,7 +88,7 @@ def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out
     part = torch.empty(rows, 2, Cc, device=y.device)
     check(lib().sed_bn_relu_pool_drop_bwd_reduce(ptr(_f32c(y)), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean),
                                                  ptr(rstd), ptr(part), B, T, F, Cc, pool_f, pool_t, int(out_tcf),
-                                                 drop_p, seed, stream_ptr()), "bn_bwd_reduce")
+                                                 drop_p, seed, None, stream_ptr()), "bn_bwd_reduce")
     sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=y.device) for _ in range(4))
     check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta),
                                     stream_ptr()), "bn_bwd_finalize")
@@ -96,7 +96,7 @@ def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out
     dbp = torch.empty(rows, Cc, device=y.device)
     check(lib().sed_bn_relu_pool_drop_bwd_apply(ptr(y), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
                                                 ptr(sum_g), ptr(sum_gx), ptr(dy), ptr(dbp), B, T, F, Cc, pool_f,
-                                                pool_t, int(out_tcf), drop_p, seed, stream_ptr()), "bn_bwd_apply")
+                                                pool_t, int(out_tcf), drop_p, seed, None, stream_ptr()), "bn_bwd_apply")
     dbias = torch.empty(Cc, device=y.device)
     check(lib().sed_reduce_rows(ptr(dbp), rows, Cc, Cc, ptr(dbias), stream_ptr()), "reduce_rows")
     return dy, dgamma, dbeta, dbias
@@ -206,9 +206,9 @@ def grad_norm_clip_coef(g, max_norm):
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, step_state=None):
     check(lib().sed_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                              ptr(grad_scale), stream_ptr()), "adam_step")
+                              ptr(grad_scale), ptr(step_state), stream_ptr()), "adam_step")
 
 
 def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p=0.0, seed=0, eps=1e-5):
@@ -226,17 +226,17 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
     mean, rstd, scale, shift = bn_finalize_train(stat, B * T * F, gamma, beta, rm, rv, eps=eps)
     out = torch.empty(B, T // pool_t, F // pool_f, Cc, device=x.device)
     check(L.sed_conv1_bn_relu_pool_drop_fwd(ptr(x), ptr(wf), ptr(bias), ptr(scale), ptr(shift), ptr(out), B, Cin, F, T, Cc,
-                                            pool_f, pool_t, drop_p, seed, stream_ptr()), "conv1_fwd")
+                                            pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_fwd")
     if dout is None:
         return out
     part = torch.empty(rows, 2, Cc, device=x.device)
     check(L.sed_conv1_bwd_reduce(ptr(x), ptr(wf), ptr(bias), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
-                                 ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, stream_ptr()), "conv1_bwd_reduce")
+                                 ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_bwd_reduce")
     sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=x.device) for _ in range(4))
     check(L.sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta), stream_ptr()), "bn_bwd_finalize")
     ws = torch.empty(L.sed_conv1_bwd_apply_workspace_bytes(B, Cin, T, Cc) // 4 + 1, device=x.device)
     dw, db = torch.empty_like(w), torch.empty(Cc, device=x.device)
     check(L.sed_conv1_bwd_apply_wgrad(ptr(x), ptr(wf), ptr(bias), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
                                       ptr(sum_g), ptr(sum_gx), ptr(dw), ptr(db), ptr(ws), B, Cin, F, T, Cc, pool_f, pool_t,
-                                      drop_p, seed, stream_ptr()), "conv1_bwd_apply_wgrad")
+                                      drop_p, seed, None, stream_ptr()), "conv1_bwd_apply_wgrad")
     return out, dw, db, dgamma, dbeta

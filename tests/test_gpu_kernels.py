@@ -161,7 +161,7 @@ def test_dropout_mask_statistics_and_backward_consistency(ops, tcf):
     dbp = torch.empty(rows, Cc).cuda()
     z = torch.zeros(Cc).cuda()
     check(lib().sed_bn_relu_pool_drop_bwd_apply(ptr(y), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(z), ptr(z),
-                                                ptr(dy), ptr(dbp), B, T, Fm, Cc, 1, 2, int(tcf), p, 1234, stream_ptr()))
+                                                ptr(dy), ptr(dbp), B, T, Fm, Cc, 1, 2, int(tcf), p, 1234, None, stream_ptr()))
     routed = dy.reshape(B, T // 2, 2, Fm, Cc).sum(2)                   # one of each time pair carries the gradient
     mask = kept.permute(0, 1, 3, 2) if tcf else kept
     close(routed, mask.float() * 2.0, atol=1e-6)

@@ -397,3 +397,31 @@ def test_cfg2_train_step_is_deterministic_and_descends(sed, cfg2_model):
     assert l1 == l2 and torch.equal(p1, p2)           # bitwise reproducible (fixed-order reductions, seeded dropout)
     assert l1[2] < l1[0]
     assert torch.isfinite(p1).all()
+
+
+def test_graph_captured_step_equals_eager_and_draws_fresh_dropout(sed):
+    """FusedTrainStep(graph=True): one hipGraph per input shape, device-side dropout salt + optimiser step"""
+    from oracle import crnn_ref
+    from sed_crnn_amd.trainer import FusedTrainStep
+    x, y = crnn_ref.synthetic_batch(8, 1, 40, 64, 8, seed=41)
+    x, y = x.cuda(), y.cuda()
+
+    def run(graph, dropout, n):
+        torch.manual_seed(17)
+        m = sed.TimePooledCRNN(conv_channels=16, dropout=dropout, gru_hidden=16).cuda()
+        st = FusedTrainStep(m, lr=1e-3, graph=graph, clip_norm=1.0)
+        losses = [st.step(x, y)[0].item() for _ in range(n)]
+        return losses, m.flat_parameters().clone()
+    le, pe = run(False, 0.0, 6)
+    lg, pg = run(True, 0.0, 6)                     # 1 eager step, capture, 5 replays: every call is one real step
+    np.testing.assert_allclose(lg, le, rtol=1e-5, atol=1e-6)
+    sig = (pe - pg).abs() < 5e-5                   # Adam(+-lr) noise entries aside (conv biases before BN)
+    assert sig.float().mean() > 0.995
+    ld, _ = run(True, 0.5, 8)
+    assert len(set(round(v, 6) for v in ld[3:])) > 1 and all(np.isfinite(ld))     # replays see different masks
+    # the salt really changes the mask: probabilities of two replays of the same weights/inputs differ under dropout
+    torch.manual_seed(3)
+    m = sed.TimePooledCRNN(conv_channels=16, dropout=0.5, gru_hidden=16).cuda()
+    st = FusedTrainStep(m, lr=0.0, graph=True)
+    pr = [st.step(x, y)[1].clone() for _ in range(5)]
+    assert not torch.equal(pr[3], pr[4])
