@@ -425,3 +425,46 @@ def test_graph_captured_step_equals_eager_and_draws_fresh_dropout(sed):
     st = FusedTrainStep(m, lr=0.0, graph=True)
     pr = [st.step(x, y)[1].clone() for _ in range(5)]
     assert not torch.equal(pr[3], pr[4])
+
+
+def test_dropout_active_parity_with_injected_masks(sed):
+    """Training-mode parity WITH dropout (p = 0.5 after every block, sed.py:92,107): the counter-hash masks of the HIP
+    run are regenerated with the stand-alone kernel and injected into the torch oracle, so logits and every gradient
+    can be compared although the two RNGs differ."""
+    import torch.nn.functional as F
+    from oracle import crnn_ref
+    from sed_crnn_amd import ops
+    torch.manual_seed(23)
+    C, H, p = 16, 16, 0.5
+    ref = crnn_ref.SedNetRef(conv_channels=C, dropout=0.0, gru_hidden=H)          # dropout applied by hand below
+    m = sed.TimePooledCRNN(conv_channels=C, dropout=p, gru_hidden=H)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=9)
+    out = m(x.cuda())
+    loss = sed.BCEWithLogitsLoss()(out, y.cuda())
+    loss.backward()
+    # regenerate the masks: block l uses seed + golden*(l+1) on the channels-last pooled index
+    golden, mask64 = 0x9E3779B97F4A7C15, (1 << 64) - 1
+    masks, T = [], 64
+    for l in range(3):
+        ones = torch.ones(4, T, 40, C).cuda()
+        mk = ops.bn_relu_pool_drop_fwd(ones, torch.ones(C).cuda(), torch.zeros(C).cuda(), 1, 2, drop_p=p,
+                                       seed=(m._seed + golden * (l + 1)) & mask64)          # [B,T/2,F,C] of {0, 2}
+        masks.append(mk.permute(0, 3, 2, 1).cpu())                                          # -> NCHW [B,C,F,T/2]
+        T //= 2
+        assert abs((mk > 0).float().mean().item() - 0.5) < 0.02
+    ref.train()
+    h = x
+    for l in range(3):
+        h = F.max_pool2d(torch.relu(ref.bns[l](ref.convs[l](h))), (1, 2)) * masks[l]
+    b, c, f, t = h.shape
+    h, _ = ref.gru(h.permute(0, 3, 1, 2).reshape(b, t, c * f))
+    out_r = ref.fc(h)
+    loss_r = crnn_ref.bce_logits(out_r, y)
+    loss_r.backward()
+    _cmp(out, out_r, atol=2e-4)
+    assert abs(loss.item() - loss_r.item()) < 1e-5
+    rg = dict(ref.named_parameters())
+    for k, q in m.named_parameters():
+        _cmp(q.grad, rg[k].grad, atol=1e-4, rtol=1e-2, msg=k)
