@@ -131,3 +131,53 @@ def test_two_rank_sync_bn_equals_single_device_on_the_global_batch():
         p.join(30)
     for r in res:
         assert all(r[1:]), r
+
+
+def _worker_rccl_single(port, q):
+    """the RCCL calls of the N>1 bench path (init, parameter broadcast, staged AVG all-reduce on the gradient arena with the
+    aux-stream backward, device-id barrier, MAX all-reduce of the timing) on a world of one rank: AVG over one rank is the
+    identity, so the run must be bit-identical to the non-distributed step"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import sed_crnn_amd as sed
+    from oracle import crnn_ref
+    from sed_crnn_amd.dist import broadcast_parameters
+    from sed_crnn_amd.trainer import FusedTrainStep
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    kw = dict(conv_channels=32, dropout=0.5, gru_hidden=32)
+    torch.manual_seed(3)
+    m = sed.TimePooledCRNN(**kw).cuda()
+    broadcast_parameters(m)
+    ref = sed.TimePooledCRNN(**kw).cuda()
+    ref.flat_parameters().copy_(m.flat_parameters())
+    x, y = crnn_ref.synthetic_batch(8, 1, 40, 64, 8, seed=9)
+    x, y = x.cuda(), y.cuda()
+    a = FusedTrainStep(m, lr=1e-3, loss="bce", clip_norm=1.0, distributed=True)
+    b = FusedTrainStep(ref, lr=1e-3, loss="bce", clip_norm=1.0, distributed=False)
+    assert a.reducer is not None and b.reducer is None
+    for _ in range(3):
+        la, _ = a.step(x, y)
+        lb, _ = b.step(x, y)
+    dist.barrier(device_ids=[0])
+    torch.cuda.synchronize()
+    t = torch.tensor([1.25], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    same_p = torch.equal(m.flat_parameters(), ref.flat_parameters())
+    same_g = torch.equal(m.flat_grads(), ref.flat_grads())
+    q.put((bool(same_p), bool(same_g), float(la.item()), float(lb.item()), float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_single_rank_staged_allreduce_is_identity():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_single, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(30)
+    assert res[0] and res[1] and res[2] == res[3] and res[4] == 1.25, res
