@@ -8,8 +8,9 @@
 //              Direct VALU convolution, HBM-bound: coalesced 16 B/lane channel-last stores,
 //              mel-band halo tile + weights staged in LDS.
 //   * mfma   : Cin%32==0, Cout%32==0 (the 128-channel layers, K = 9*Cin = 1152): implicit GEMM
-//              on v_mfma_f32_32x32x2_f32 (exact fp32), (TT+2)x(F+2) halo tile of 32 input
-//              channels in LDS read with conflict-free ds_read_b128, weights double-buffered.
+//              on v_mfma_f32_32x32x2_f32 (exact fp32), (TT+2)x(FT+2) halo tile of 32 input
+//              channels in LDS read with conflict-free ds_read_b128 (TT time rows x FT mel columns per
+//              block, any mel width), weights streamed L2 -> registers in MFMA fragment order.
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
 #include "common.h"
@@ -17,44 +18,58 @@
 #define CV_CIC 32   // input channels per LDS chunk
 #define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
 #define CV_MTW 5    // max 32-row tiles per wave
-#define WG_NX 6      // wgrad: max float4 per thread of the halo tile   ((TT+2)*(F+2)*8 <= 256*WG_NX)
-#define WG_ND 10     // wgrad: max float4 per thread of the dY tile      (TT*F*32      <= 256*WG_ND)
-#define WG_NX2 8     // wgrad mode 2 (4-row tiles)
-#define WG_ND2 20
+#define WG_FT 40     // wgrad: max mel columns per tile (4 time rows)
+#define WG_NX 8      // wgrad: float4 per thread of the halo tile   (6*(WG_FT+2)*8 <= 256*WG_NX)
+#define WG_ND 20     // wgrad: float4 per thread of the dY tile     (4*WG_FT*32    <= 256*WG_ND)
 
-#define CV_TPAD 56   // fwd v2: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
-#define CV_NH 8      // fwd v2: max float4 per thread of the halo tile ((TT+2)*(F+2)*8 <= 256*CV_NH)
+#define CV_TPAD 56   // fwd: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
+#define CV_NH 8      // fwd: max float4 per thread of the halo tile ((TT+2)*(FT+2)*8 <= 256*CV_NH)
 
 struct ConvPlan {
-    int v2;         // mfma: register-streamed weights + double-buffered halo
     int kind;       // 0 small, 1 mfma, -1 unsupported
     int TT;         // time rows per block tile
+    int FT, nft;    // mfma: mel columns per block tile, mel tiles (FT == F, nft == 1 on the small path)
     int nct;        // mfma: 32-wide co tiles per block
     int tblocks;    // ceil(T/TT)
-    int rows;       // stat partial rows = B * tblocks
+    int rows;       // stat partial rows = B * tblocks * nft
     size_t lds;
 };
+
+// MFMA block tile: TT time rows x FT mel columns (+1 halo each side) with TT*FT <= limit output rows (every wave always
+// runs its CV_MTW 32-row tiles, so rows below the limit are idle MFMA cycles) and at most 256*CV_NH/8 halo rows.
+// Score = useful share of the MFMA rows (tile fill x mel coverage x time coverage), discounted by the halo share that is
+// staged per tile; measured on MI355X at F=128: 32x5 125 TFLOP/s, 26x6 119, 32x4 102, 64x1 54.
+static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nft_out) {
+    double best = -1.0;
+    int last_ft = -1;
+    for (int nft = 1; nft <= F; ++nft) {
+        int FT = cdiv(F, nft);
+        FT += FT & 1;                                    // even (the weight-gradient kernel walks mel pairs)
+        if (FT == last_ft) continue;
+        last_ft = FT;
+        const int nf = cdiv(F, FT);
+        for (int TT = 1; TT <= 8 && TT <= T; ++TT) {
+            if (TT * FT > limit || (TT + 2) * (FT + 2) * 8 > 256 * CV_NH) continue;
+            double util = ((double)(TT * FT) / limit) * ((double)F / ((double)nf * FT)) * ((double)T / ((double)cdiv(T, TT) * TT));
+            double score = util / (1.0 + 0.25 * ((double)(TT + 2) * (FT + 2) / (TT * FT) - 1.0));
+            if (score > best) { best = score; *TT_out = TT; *FT_out = FT; *nft_out = nf; }
+        }
+        if (FT <= 2) break;
+    }
+    return best > 0.0;
+}
 
 static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
     ConvPlan p{};
     p.kind = -1;
+    p.FT = F; p.nft = 1;
     if (!x_is_nchw && Cin % CV_CIC == 0 && Cout % 32 == 0) {
         int nct = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0 ? 2 : 1);
         int mparts = 4 / nct;
         int limit = 32 * CV_MTW * mparts;
-        if (F <= limit) {
-            int TT = limit / F;
-            if (TT > T) TT = T;
-            if (TT > 8) TT = 8;
-            p.kind = 1; p.TT = TT; p.nct = nct;
-            p.lds = ((size_t)(TT + 2) * (F + 2) * CV_LD + 2 * 32 * nct * CV_LD) * sizeof(float);
-            if ((TT + 2) * (F + 2) * 8 <= 256 * CV_NH) {
-                p.v2 = 1;
-                p.lds = (size_t)2 * (TT + 2) * ((F + 2) * CV_LD + CV_TPAD) * sizeof(float);
-            }
-        } else {
-            return p;     // MFMA-sized channels but a mel axis wider than one block tile: unsupported
-        }
+        if (!conv_tile(F, T, limit, &p.TT, &p.FT, &p.nft)) return p;
+        p.kind = 1; p.nct = nct;
+        p.lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
     }
     if (p.kind < 0) {
         if (Cout % 4 != 0) return p;
@@ -67,7 +82,7 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
         p.kind = 0; p.TT = TT; p.nct = 0; p.lds = lds;
     }
     p.tblocks = cdiv(T, p.TT);
-    p.rows = B * p.tblocks;
+    p.rows = B * p.tblocks * p.nft;
     return p;
 }
 
@@ -182,167 +197,33 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
 }
 
 // ───────────────────────── MFMA implicit-GEMM forward ─────────────────────────
-// grid (ceil(T/TT), B, Cout/(32*NCT)); 256 threads = 4 waves.
+// grid (ceil(T/TT) * nft, B, Cout/(32*NCT)); 256 threads = 4 waves; block tile = TT time rows x FT mel columns.
 // wave w: co tile ct = w % NCT, row part mp = w / NCT; row tiles mt = mp + i*(4/NCT).
-template <int NCT>
-__global__ __launch_bounds__(256) void conv3x3_mfma_fwd_k(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
-    constexpr int MPARTS = 4 / NCT;
-    constexpr int WROWS = 32 * NCT;                 // weight rows (co) per block
-    constexpr int WV4 = WROWS * 8 / 256;            // float4 per thread per weight tile (= NCT)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int F2 = F + 2;
-    const int HR = (TT + 2) * F2;
-    float* halo = smem;                             // [HR][CV_LD]
-    float* wbuf = smem + HR * CV_LD;                // [2][WROWS][CV_LD]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
-    const int ct = wave % NCT, mp = wave / NCT;
-    const int MROWS = TT * F;
-    const int nMT = (MROWS + 31) >> 5;
-
-    int abase[CV_MTW];
-#pragma unroll
-    for (int i = 0; i < CV_MTW; ++i) {
-        int p = (mp + i * MPARTS) * 32 + r;
-        if (p >= MROWS) p = MROWS - 1;
-        int tl = p / F, f = p - tl * F;
-        abase[i] = (tl * F2 + f) * CV_LD + 4 * h;
-    }
-    const int bbase = (ct * 32 + r) * CV_LD + 4 * h;
-
-    f32x16 acc[CV_MTW];
-#pragma unroll
-    for (int i = 0; i < CV_MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-    const int nchunks = Cin / CV_CIC;
-    for (int cc = 0; cc < nchunks; ++cc) {
-        __syncthreads();
-        // stage the halo tile of this 32-channel chunk (zero padded)
-        for (int i = tid; i < HR * 8; i += 256) {
-            int row = i >> 3, q = i & 7;
-            int tt = row / F2, ff = row - tt * F2;
-            int t = t0 + tt - 1, f = ff - 1;
-            f32x4 v = {0, 0, 0, 0};
-            if (t >= 0 && t < T && f >= 0 && f < F)
-                v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
-            *(f32x4*)(halo + row * CV_LD + q * 4) = v;
-        }
-        // weights of tap 0
-#pragma unroll
-        for (int u = 0; u < WV4; ++u) {
-            int i = tid + u * 256, row = i >> 3, q = i & 7;
-            f32x4 v = *(const f32x4*)(wp + conv_frag_index(0, co0 + row, cc * CV_CIC + q * 4, Cout, Cin));
-            *(f32x4*)(wbuf + row * CV_LD + q * 4) = v;
-        }
-        __syncthreads();
-        for (int tap = 0; tap < 9; ++tap) {
-            f32x4 wn[WV4];
-            if (tap < 8) {
-#pragma unroll
-                for (int u = 0; u < WV4; ++u) {
-                    int i = tid + u * 256, row = i >> 3, q = i & 7;
-                    wn[u] = *(const f32x4*)(wp + conv_frag_index(tap + 1, co0 + row, cc * CV_CIC + q * 4, Cout, Cin));
-                }
-            }
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = (kw * F2 + kh) * CV_LD;
-            const float* wb = wbuf + (tap & 1) * WROWS * CV_LD + bbase;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 bf = *(const f32x4*)(wb + g * 8);
-                f32x4 af[CV_MTW];
-#pragma unroll
-                for (int i = 0; i < CV_MTW; ++i)
-                    af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < CV_MTW; ++i)      // tiles past nMT read clamped rows and are never stored
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[j], acc[i], 0, 0, 0);
-            }
-            if (tap < 8) {
-                float* wdst = wbuf + ((tap + 1) & 1) * WROWS * CV_LD;
-#pragma unroll
-                for (int u = 0; u < WV4; ++u) {
-                    int i = tid + u * 256, row = i >> 3, q = i & 7;
-                    *(f32x4*)(wdst + row * CV_LD + q * 4) = wn[u];
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // epilogue: bias, channel-last store, BatchNorm partial sums
-    const int co = co0 + ct * 32 + r;
-    const float bv = bias ? bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < CV_MTW; ++i) {
-        int mt = mp + i * MPARTS;
-        if (mt < nMT) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-                int p = mt * 32 + row;
-                int tl = p / F, f = p - tl * F;
-                if (p < MROWS && t0 + tl < T) {
-                    float v = acc[i][j] + bv;
-                    y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
-                    s1 += v;
-                    s2 += v * v;
-                }
-            }
-        }
-    }
-    if (stat) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        __syncthreads();
-        float* red = smem;                          // [4 waves][2][32]
-        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
-        __syncthreads();
-        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
-        if (tid < 2 * WROWS) {
-            int which = tid / WROWS, c = tid - which * WROWS;       // c in [0, 32*NCT)
-            int cti = c >> 5, cr = c & 31;
-            float a = 0.f;
-#pragma unroll
-            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
-            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
-        }
-    }
-}
-
-// ── v2: weights streamed L2 -> registers in fragment order (one coalesced 1 KiB load per wave and k-group, no LDS,
-// no per-tap barrier), halo tile double-buffered in LDS with the next chunk's global loads issued before the
-// MFMA loop of the current one: one barrier per 32-channel chunk (4 per block instead of 40).
+// Weights are streamed L2 -> registers in fragment order (one coalesced 1 KiB load per wave and k-group, no LDS, no
+// per-tap barrier); the halo tile is double-buffered in LDS with the next 32-channel chunk's global loads issued before
+// the MFMA loop of the current one: one barrier per chunk.
 template <int NCT, int MINW>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft) {
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int F2 = F + 2;
+    const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
     // LDS pitch of one halo time-row: F2 rows of CV_LD floats + CV_TPAD.  The pad makes the 16-B slot of flattened
-    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = F*9 mod 16),
+    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = FT*9 mod 16),
     // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
     const int TP = F2 * CV_LD + CV_TPAD;
     const int HB = (TT + 2) * TP;
-    const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y, t0 = blockIdx.x * TT, co0 = blockIdx.z * WROWS;
+    const int tb = blockIdx.x / nft, f0 = (blockIdx.x - tb * nft) * FT;
+    const int b = blockIdx.y, t0 = tb * TT, co0 = blockIdx.z * WROWS;
     const int ct = wave % NCT, mp = wave / NCT;
-    const int MROWS = TT * F;
+    const int MROWS = TT * FT;
     const int nMT = (MROWS + 31) >> 5;
     const int nchunks = Cin / CV_CIC, ncot = Cout >> 5, cot = blockIdx.z * NCT + ct;
 
@@ -351,7 +232,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     for (int i = 0; i < CV_MTW; ++i) {
         int p = (mp + i * MPARTS) * 32 + r;
         if (p >= MROWS) p = MROWS - 1;
-        int tl = sed_fdiv(p, invF), f = p - tl * F;
+        int tl = sed_fdiv(p, invF), f = p - tl * FT;
         abase[i] = tl * TP + f * CV_LD + 4 * h;
     }
     f32x16 acc[CV_MTW];
@@ -376,7 +257,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             if (i < HR * 8) {
                 int row = i >> 3, q = i & 7;
                 int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-                int t = t0 + tt - 1, f = ff - 1;
+                int t = t0 + tt - 1, f = f0 + ff - 1;
                 if (t >= 0 && t < T && f >= 0 && f < F)
                     v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
             }
@@ -441,8 +322,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             for (int j = 0; j < 16; ++j) {
                 int row = (j & 3) + 8 * (j >> 2) + 4 * h;
                 int p = mt * 32 + row;
-                int tl = sed_fdiv(p, invF), f = p - tl * F;
-                if (p < MROWS && t0 + tl < T) {
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                if (p < MROWS && t0 + tl < T && f < F) {
                     float v = acc[i][j] + bv;
                     y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
                     s1 += v;
@@ -497,28 +378,16 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
         SED_TRY(set_lds(conv3x3_small_fwd_k, p.lds));
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
-        dim3 grid(p.tblocks, B, Cout / (32 * p.nct));
-        if (p.v2) {
-            if (p.nct == 4) {
-                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
-            } else if (p.nct == 2) {
-                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
-            } else {
-                SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
-                conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
-            }
-        } else if (p.nct == 4) {
-            p.lds = ((size_t)(p.TT + 2) * (F + 2) * CV_LD + 2 * 32 * p.nct * CV_LD) * sizeof(float);
-            SED_TRY(set_lds(conv3x3_mfma_fwd_k<4>, p.lds));
-            conv3x3_mfma_fwd_k<4><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+        dim3 grid(p.tblocks * p.nft, B, Cout / (32 * p.nct));
+        if (p.nct == 4) {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
         } else if (p.nct == 2) {
-            SED_TRY(set_lds(conv3x3_mfma_fwd_k<2>, p.lds));
-            conv3x3_mfma_fwd_k<2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
         } else {
-            SED_TRY(set_lds(conv3x3_mfma_fwd_k<1>, p.lds));
-            conv3x3_mfma_fwd_k<1><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
         }
     }
     SED_LAUNCH_CHECK("conv3x3_fwd");
@@ -528,35 +397,23 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
 // ───────────────────────── weight gradient ─────────────────────────
 struct WgradPlan {
     int kind;        // 0 small, 1 mfma
-    int db;          // mfma: double-buffered variant
-    int TT, ntiles, ngroups, tblocks;
+    int TT, FT, nft; // block tile: TT time rows x FT mel columns, nft mel tiles (mfma); FT == F on the small path
+    int ntiles, ngroups, tblocks;
     size_t lds, slab_floats;
 };
 
 static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
     WgradPlan p{};
-    p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0 && (F % 2 == 0)) ? 1 : 0;
-    if (p.kind == 1 && T >= 4 && (6 * (F + 2) * 8) <= 256 * WG_NX2 && 4 * F * 32 <= 256 * WG_ND2 &&
-        ((size_t)6 * (F + 2) * 32 + (size_t)4 * F * 128) * sizeof(float) <= 150 * 1024) {
-        p.TT = 4;                               // mode 2: single LDS buffer, next tile held in registers
-        p.db = 2;
-        p.lds = ((size_t)6 * (F + 2) * 32 + (size_t)4 * F * 128) * sizeof(float);
-    } else if (p.kind == 1) {
-        p.TT = 2;
-        if (p.TT > T) p.TT = T;
-        p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
-        if (p.lds > 150 * 1024) {               // wide mel axis (F = 128): one time row per tile
-            p.TT = 1;
-            p.lds = ((size_t)(p.TT + 2) * (F + 2) * 32 + (size_t)p.TT * F * 128) * sizeof(float);
-        }
-        if ((p.TT * F) % 2) p.kind = 0;
-        if (p.lds > 150 * 1024) p.kind = 0;
-        else if (2 * p.lds <= 156 * 1024 && (p.TT + 2) * (F + 2) * 8 <= 256 * WG_NX && p.TT * F * 32 <= 256 * WG_ND) {
-            p.db = 1;
-            p.lds *= 2;
-        }
-    }
-    if (p.kind == 0) {
+    p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
+    p.FT = F; p.nft = 1;
+    if (p.kind == 1) {
+        // 4 time rows x (even) FT <= WG_FT mel columns: the staging register budget of the kernel (WG_NX / WG_ND)
+        p.TT = 4;
+        p.nft = cdiv(F, WG_FT);
+        p.FT = cdiv(F, p.nft);
+        p.FT += p.FT & 1;
+        p.lds = ((size_t)6 * (p.FT + 2) * 32 + (size_t)4 * p.FT * 128) * sizeof(float);
+    } else {
         p.TT = 4;
         if (p.TT > T) p.TT = T;
         size_t a = (((size_t)(p.TT + 2) * (F + 2) + 3) & ~(size_t)3) * sizeof(float);
@@ -564,9 +421,9 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
         p.lds = a + red;
     }
     p.tblocks = cdiv(T, p.TT);
-    p.ntiles = B * p.tblocks;
-    // mfma db: one resident block per CU at Cin=128; small (HBM-bound): enough blocks to fill every CU 4x
-    const int maxg = (p.kind == 1) ? (p.db ? 64 : 128) : 1024;
+    p.ntiles = B * p.tblocks * p.nft;
+    // mfma: one resident block per CU at Cin=128 (grid = ngroups x Cin/32); small (HBM-bound): enough blocks to fill every CU 4x
+    const int maxg = (p.kind == 1) ? 64 : 1024;
     p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
     p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
     return p;
@@ -656,23 +513,22 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* _
 
 // mfma: grid (ngroups, Cin/32, Cout/128); slabs [group][9][Cin][Cout]
 // D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions.
-// DB=true: both LDS tiles are double-buffered and the next tile's global loads are issued before the
-// MFMA loop of the current one (register prefetch, NX+ND float4 per thread), one barrier per tile.
-// MODE 0: plain staging (any shape that fits LDS)   1: double-buffered 2-row tiles   2: single-buffered 4-row tiles with
-// the whole next tile prefetched into registers (staging cost amortised over twice the MFMA work; ablation: staging was
-// 12 % of the kernel at 2-row tiles)
-template <int MODE>
+// A block walks tiles of TT = 4 time rows x FT mel columns.  One LDS buffer; the whole next tile is prefetched into
+// registers (WG_NX + WG_ND float4 per thread) before the MFMA loop of the current one and written to LDS after it, so
+// the staging cost is amortised over 4*FT positions (ablation: staging was 12 % of the kernel at 2-row tiles).
+// MT = false: one mel tile (FT >= F), the padding columns are fixed per block; MT = true: mel-tiled (any F),
+// the mel range test of every staged float4 depends on the tile.
+template <bool MT>
 __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
-    int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    int B, int Cin, int F, int T, int Cout, int FT, int nft, int tblocks, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int F2 = F + 2;
+    constexpr int TT = 4, NX = WG_NX, ND = WG_ND;
+    const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
-    const int MROWS = TT * F;
-    constexpr bool DB = MODE != 0;
-    constexpr int NX = MODE == 2 ? WG_NX2 : WG_NX, ND = MODE == 2 ? WG_ND2 : WG_ND;
-    const int XH = HR * 32, DYS = MROWS * 128, BUF = XH + DYS;
-    const float invF = 1.0f / (float)F, invF2 = 1.0f / (float)F2;
+    const int MROWS = TT * FT;
+    const int XH = HR * 32;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
@@ -683,43 +539,54 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-    f32x4 px[DB ? NX : 1], pd[DB ? ND : 1];
+    f32x4 px[NX], pd[ND];
     // tile-invariant part of the staging addresses, computed once per block: element offset from the tile origin
-    // (b, t0, f = 0) and the time row it belongs to (-1: padding or out of the tile); per tile only a base pointer,
-    // one add and one range test per float4 remain (the index math otherwise runs with the MFMA pipe idle)
-    int xo[DB ? NX : 1], xt[DB ? NX : 1], dofs[DB ? ND : 1], dt[DB ? ND : 1];
-    if (DB) {
+    // (b, t0, f0) and where the float4 sits in the tile; per tile only a base pointer, one add and the range tests
+    // remain (the index math otherwise runs with the MFMA pipe idle).
+    //   MT = false: xt = time row (-1..4; a huge negative marks padding / out of the tile), dt = time row (huge: none)
+    //   MT = true : xt = tt | ff << 3 (halo coordinates), dt = tl | fl << 2, with ff / fl huge for "none"
+    int xo[NX], xt[NX], dofs[ND], dt[ND];
 #pragma unroll
-        for (int u = 0; u < NX; ++u) {
-            int i = tid + u * 256, row = i >> 3, q = i & 7;
-            int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-            bool ok = i < HR * 8 && ff >= 1 && ff <= F;
-            xt[u] = ok ? tt - 1 : -(1 << 20);
-            xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
-        }
+    for (int u = 0; u < NX; ++u) {
+        int i = tid + u * 256, row = i >> 3, q = i & 7;
+        int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+        if (MT) xt[u] = (i < HR * 8) ? (tt | (ff << 3)) : (1 << 24);
+        else xt[u] = (i < HR * 8 && ff >= 1 && ff <= F) ? tt - 1 : -(1 << 20);
+        xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
+    }
 #pragma unroll
-        for (int u = 0; u < ND; ++u) {
-            int i = tid + u * 256, row = i >> 5, q = i & 31;
-            int tl = sed_fdiv(row, invF);
-            dt[u] = (i < MROWS * 32) ? tl : (1 << 20);
-            dofs[u] = row * Cout + co0 + q * 4;                     // (tl*F + f) == row
-        }
+    for (int u = 0; u < ND; ++u) {
+        int i = tid + u * 256, row = i >> 5, q = i & 31;
+        int tl = sed_fdiv(row, invF), fl = row - tl * FT;
+        if (MT) dt[u] = (i < MROWS * 32) ? (tl | (fl << 2)) : (1 << 24);
+        else dt[u] = (i < MROWS * 32 && fl < F) ? tl : (1 << 20);
+        dofs[u] = (tl * F + fl) * Cout + co0 + q * 4;
     }
     auto fetch = [&](int tile) {          // global -> registers
-        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
-        const float* xb = x + ((size_t)b * T + t0) * F * Cin;
-        const float* db = dy + ((size_t)b * T + t0) * F * Cout;
+        int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
+        int tb = rem / nft, f0 = (rem - tb * nft) * FT, t0 = tb * TT;
+        const float* xb = x + (((size_t)b * T + t0) * F + f0) * Cin;
+        const float* db = dy + (((size_t)b * T + t0) * F + f0) * Cout;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
             f32x4 v = {0, 0, 0, 0};
-            int t = t0 + xt[u];
-            if (t >= 0 && t < T) v = *(const f32x4*)(xb + xo[u]);
+            if (MT) {
+                int t = t0 + (xt[u] & 7) - 1, f = f0 + (xt[u] >> 3) - 1;
+                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F) v = *(const f32x4*)(xb + xo[u]);
+            } else {
+                int t = t0 + xt[u];
+                if (t >= 0 && t < T) v = *(const f32x4*)(xb + xo[u]);
+            }
             px[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
             f32x4 v = {0, 0, 0, 0};
-            if (t0 + dt[u] < T) v = *(const f32x4*)(db + dofs[u]);
+            if (MT) {
+                if (t0 + (dt[u] & 3) < T && f0 + (dt[u] >> 2) < F) v = *(const f32x4*)(db + dofs[u]);
+            } else {
+                if (t0 + dt[u] < T) v = *(const f32x4*)(db + dofs[u]);
+            }
             pd[u] = v;
         }
     };
@@ -739,11 +606,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         const float* xh = buf;
         const float* dys = buf + XH;
         // one wave per SIMD: the LDS operands of k-step fs+1 are read while the 9 MFMAs of step fs issue
-        // (explicit two-stage register pipeline; position p = tl*F + 2*fs + h)
-        const int nfs = F >> 1;
+        // (explicit two-stage register pipeline; position p = tl*FT + 2*fs + h)
+        const int nfs = FT >> 1;
         for (int tl = 0; tl < TT; ++tl) {
             const float* xrow = xh + (tl * F2 + h) * 32 + r;
-            const float* drow = dys + (tl * F + h) * 128 + wave * 32 + r;
+            const float* drow = dys + (tl * FT + h) * 128 + wave * 32 + r;
             float a0[9], a1[9], b0, b1;
             auto ld = [&](int fs, float* a, float& bq) {
                 const float* xp = xrow + fs * 64;
@@ -770,53 +637,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         }
     };
 
-    if (MODE == 2) {
-        int tile = blockIdx.x;
-        if (tile < ntiles) { fetch(tile); commit(smem); }
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); commit(smem); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt);
+        compute(smem);
+        __syncthreads();                       // every wave is done reading the tile
+        if (nxt < ntiles) commit(smem);
         __syncthreads();
-        for (; tile < ntiles; tile += gridDim.x) {
-            const int nxt = tile + gridDim.x;
-            if (nxt < ntiles) fetch(nxt);
-            compute(smem);
-            __syncthreads();                       // every wave is done reading the tile
-            if (nxt < ntiles) commit(smem);
-            __syncthreads();
-        }
-    } else if (MODE == 1) {
-        int tile = blockIdx.x, cur = 0;
-        if (tile < ntiles) { fetch(tile); commit(smem); }
-        __syncthreads();
-        for (; tile < ntiles; tile += gridDim.x) {
-            const int nxt = tile + gridDim.x;
-            if (nxt < ntiles) fetch(nxt);
-            compute(smem + cur * BUF);
-            if (nxt < ntiles) commit(smem + (cur ^ 1) * BUF);
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
-            __syncthreads();
-            for (int i = tid; i < HR * 8; i += 256) {
-                int row = i >> 3, q = i & 7;
-                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-                int t = t0 + tt - 1, f = ff - 1;
-                f32x4 v = {0, 0, 0, 0};
-                if (t >= 0 && t < T && f >= 0 && f < F)
-                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + ci0 + q * 4);
-                *(f32x4*)(smem + i * 4) = v;
-            }
-            for (int i = tid; i < MROWS * 32; i += 256) {
-                int row = i >> 5, q = i & 31;
-                int tl = sed_fdiv(row, invF), f = row - tl * F;
-                f32x4 v = {0, 0, 0, 0};
-                if (t0 + tl < T) v = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + q * 4);
-                *(f32x4*)(smem + XH + i * 4) = v;
-            }
-            __syncthreads();
-            compute(smem);
-        }
     }
     // D rows = ci, cols = co
     float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
@@ -854,15 +684,12 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
                       p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
     if (p.kind == 1) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
-        if (p.db == 2) {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<2>, p.lds));
-            conv3x3_mfma_wgrad_k<2><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
-        } else if (p.db == 1) {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<1>, p.lds));
-            conv3x3_mfma_wgrad_k<1><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        if (p.nft == 1) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
+            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.FT, p.nft, p.tblocks, p.ntiles);
         } else {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<0>, p.lds));
-            conv3x3_mfma_wgrad_k<0><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
+            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.FT, p.nft, p.tblocks, p.ntiles);
         }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);

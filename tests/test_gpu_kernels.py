@@ -29,6 +29,9 @@ CONV_CASES = [  # B, Cin, F, T, Cout, nchw
     (2, 8, 40, 8, 8, False), (2, 16, 40, 10, 16, False),
     (2, 128, 40, 12, 128, False), (1, 128, 40, 7, 128, False), (2, 32, 40, 8, 32, False), (2, 64, 20, 8, 64, False),
     (1, 128, 128, 4, 128, False), (2, 128, 40, 8, 256, False), (2, 128, 128, 3, 128, False),
+    # mel axis wider than one block tile / not a multiple of the tile / odd; time extents that leave ragged last tiles
+    (1, 128, 128, 11, 128, False), (1, 128, 50, 5, 128, False), (1, 128, 41, 6, 128, False), (1, 128, 200, 2, 128, False),
+    (1, 32, 90, 9, 32, False), (1, 64, 130, 3, 64, False), (2, 128, 7, 5, 128, False), (1, 128, 40, 1, 128, False),
 ]
 
 
