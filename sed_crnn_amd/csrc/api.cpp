@@ -1,6 +1,7 @@
 // api.cpp — library-level entry points: version, thread-local error string, measurement timers.
 #include <stdarg.h>
 #include <stdio.h>
+#include <mutex>
 #include <vector>
 #include "common.h"
 
@@ -22,6 +23,7 @@ namespace {
 struct Rec { int tag; hipEvent_t a, b; double units; };
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
+std::mutex g_prof_mu;                  // the timers are a measurement aid, but entries may be called from several threads
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
@@ -34,16 +36,19 @@ const char* kNames[SED_K_COUNT] = {"conv3x3_mfma_fwd", "conv3x3_small_fwd", "con
 }  // namespace
 
 void sed_prof_begin(int tag, hipStream_t s, double units) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     Rec r{tag, get_event(), get_event(), units};
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
 }
 void sed_prof_end(int tag, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (size_t i = g_recs.size(); i-- > 0;)
         if (g_recs[i].tag == tag) { (void)hipEventRecord(g_recs[i].b, s); return; }
 }
 
 extern "C" int sed_prof_enable(unsigned mask) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_recs.clear();
     g_sed_prof_mask = mask;
@@ -54,6 +59,7 @@ extern "C" int sed_prof_read(int tag, double* total_ms, long* launches, double* 
     SED_REQUIRE(tag >= 0 && tag < SED_K_COUNT, "prof_read: bad tag %d", tag);
     double ms = 0, units = 0;
     long n = 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_recs) {
         if (r.tag != tag) continue;
         hipError_t e = hipEventSynchronize(r.b);

@@ -4,6 +4,7 @@
 // sed.py:101-103,111-112; crnn_lightning.py:61-64,71-73) and their autograd transposes.
 // The GRU input projection (M=B*T', K=C*F, N=3H) is the one genuine dense GEMM of the path, hence MFMA.
 // fp32 in / fp32 accumulate: bit-for-bit a k-ordered fmaf chain, no reduced precision.
+#include <type_traits>
 #include "common.h"
 
 #define GM_BK 32
@@ -11,8 +12,12 @@
 
 // A_KC / B_KC: operand is contiguous along k (true) or along m/n (false).
 // Block tile (32*WM*WVM) x (32*WN*WVN), 4 waves as WVM x WVN, each wave WM x WN tiles of 32x32 (v_mfma_f32_32x32x2_f32).
-// LDS tiles are double-buffered: the next K-step's global loads are issued before the MFMA block of the
-// current one and written to the other buffer after it; one barrier per K-step of 32.
+// Three-stage pipeline per K-step of 32: registers hold step k+1 (global loads issued a whole step earlier), LDS buffer
+// `cur` holds step k.  Each iteration first writes the registers to the other LDS buffer and issues the loads of step
+// k+2, then runs the MFMA block of step k, so the LDS writes and the global latency are covered by MFMA work and the one
+// barrier per step has nothing outstanding.  Inside a step the fragments of k-group g+1 are read while the MFMAs of
+// group g issue.  FULL = interior tile with aligned operands and K a multiple of 32: loads without range tests (the
+// guarded variant costs ~1000 scalar/branch instructions per step, which a lone wave per SIMD cannot hide).
 template <bool KC, int NR, int TILE>
 __device__ __forceinline__ void gm_load(f32x4* reg, const float* __restrict__ P, long s_mn, long s_k, int mn0, int MN,
                                         int K, int vec, int k0, int tid) {
@@ -23,8 +28,8 @@ __device__ __forceinline__ void gm_load(f32x4* reg, const float* __restrict__ P,
         if (KC) {
             int row = i >> 3, kq = i & 7;
             int m = mn0 + row, k = k0 + kq * 4;
+            const float* p = P + (long)m * s_mn + k;
             if (m < MN) {
-                const float* p = P + (long)m * s_mn + k;
                 if (vec && k + 3 < K) v = *(const f32x4*)p;
                 else
 #pragma unroll
@@ -33,8 +38,8 @@ __device__ __forceinline__ void gm_load(f32x4* reg, const float* __restrict__ P,
         } else {
             int kk = i / (TILE / 4), mq = i - kk * (TILE / 4);
             int m = mn0 + mq * 4, k = k0 + kk;
+            const float* p = P + (long)k * s_k + m;
             if (k < K) {
-                const float* p = P + (long)k * s_k + m;
                 if (vec && m + 3 < MN) v = *(const f32x4*)p;
                 else
 #pragma unroll
@@ -74,7 +79,18 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, so the
+    // launch index is mapped to a tile such that every XCD walks a contiguous run of tiles in row-major order: the column
+    // tiles that share an A row-tile meet in one L2 instead of eight.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        const int q = total >> 3, rr = total & 7, xcd = id & 7, seq = id >> 3;
+        const int v = (xcd < rr) ? xcd * (q + 1) + seq : rr * (q + 1) + (xcd - rr) * q + seq;
+        by = v / (int)gridDim.x;
+        bx = v - by * (int)gridDim.x;
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int wm0 = (wave / WVN) * 32 * WM, wn0 = (wave % WVN) * 32 * WN;
 
     f32x16 acc[WM][WN];
@@ -85,53 +101,104 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[t][u][j] = 0.f;
 
-    f32x4 ra[NA], rb[NB];
-    gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, kb, tid);
-    gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, kb, tid);
-    gm_store<A_KC, NA, BM>(ra, As0, tid);
-    gm_store<B_KC, NB, BN>(rb, Bs0, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kb; k0 < K; k0 += GM_BK) {
-        const bool more = k0 + GM_BK < K;
-        if (more) {
-            gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, k0 + GM_BK, tid);
-            gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, k0 + GM_BK, tid);
+    auto read_frags = [&](const float* As, const float* Bs, int g, f32x4* af, f32x4* bf) {
+#pragma unroll
+        for (int t = 0; t < WM; ++t) {
+            if (A_KC) af[t] = *(const f32x4*)(As + (wm0 + t * 32 + r) * GM_LDK + g * 8 + 4 * h);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[t][j] = As[(g * 8 + 4 * h + j) * BM + wm0 + t * 32 + r];
         }
-        const float* As = As0 + cur * A_FLOATS;
-        const float* Bs = Bs0 + cur * B_FLOATS;
 #pragma unroll
-        for (int g = 0; g < GM_BK / 8; ++g) {
-            f32x4 af[WM], bf[WN];
+        for (int u = 0; u < WN; ++u) {
+            if (B_KC) bf[u] = *(const f32x4*)(Bs + (wn0 + u * 32 + r) * GM_LDK + g * 8 + 4 * h);
+            else
 #pragma unroll
-            for (int t = 0; t < WM; ++t) {
-                if (A_KC) af[t] = *(const f32x4*)(As + (wm0 + t * 32 + r) * GM_LDK + g * 8 + 4 * h);
-                else
+                for (int j = 0; j < 4; ++j) bf[u][j] = Bs[(g * 8 + 4 * h + j) * BN + wn0 + u * 32 + r];
+        }
+    };
+    auto mfma_group = [&](const f32x4* af, const f32x4* bf) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) af[t][j] = As[(g * 8 + 4 * h + j) * BM + wm0 + t * 32 + r];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < WM; ++t)
+#pragma unroll
+                for (int u = 0; u < WN; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
+    };
+
+    auto run = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        f32x4 ra[NA], rb[NB];
+        // FULL: per-thread source pointers, advanced by one K-step per load (two VALU adds instead of the full index math)
+        const float* pa[NA];
+        const float* pb[NB];
+        const long a_step = A_KC ? GM_BK : GM_BK * a_sk, b_step = B_KC ? GM_BK : GM_BK * b_sk;
+        if (FULL) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                int i = tid + u * 256;
+                if (A_KC) pa[u] = A + (long)(m0 + (i >> 3)) * a_si + kb + (i & 7) * 4;
+                else { int kk = i / (BM / 4), mq = i - kk * (BM / 4); pa[u] = A + (long)(kb + kk) * a_sk + m0 + mq * 4; }
             }
 #pragma unroll
-            for (int u = 0; u < WN; ++u) {
-                if (B_KC) bf[u] = *(const f32x4*)(Bs + (wn0 + u * 32 + r) * GM_LDK + g * 8 + 4 * h);
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bf[u][j] = Bs[(g * 8 + 4 * h + j) * BN + wn0 + u * 32 + r];
+            for (int u = 0; u < NB; ++u) {
+                int i = tid + u * 256;
+                if (B_KC) pb[u] = Bm + (long)(n0 + (i >> 3)) * b_sj + kb + (i & 7) * 4;
+                else { int kk = i / (BN / 4), mq = i - kk * (BN / 4); pb[u] = Bm + (long)(kb + kk) * b_sk + n0 + mq * 4; }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < WM; ++t)
-#pragma unroll
-                    for (int u = 0; u < WN; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][j], bf[u][j], acc[t][u], 0, 0, 0);
         }
-        if (more) {
-            gm_store<A_KC, NA, BM>(ra, As0 + (cur ^ 1) * A_FLOATS, tid);
-            gm_store<B_KC, NB, BN>(rb, Bs0 + (cur ^ 1) * B_FLOATS, tid);
-        }
+        auto load = [&](int k0) {
+            if (FULL) {
+#pragma unroll
+                for (int u = 0; u < NA; ++u) { ra[u] = *(const f32x4*)pa[u]; pa[u] += a_step; }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { rb[u] = *(const f32x4*)pb[u]; pb[u] += b_step; }
+            } else {
+                gm_load<A_KC, NA, BM>(ra, A, a_si, a_sk, m0, M, K, a_vec, k0, tid);
+                gm_load<B_KC, NB, BN>(rb, Bm, b_sj, b_sk, n0, N, K, b_vec, k0, tid);
+            }
+        };
+        auto store = [&](int buf) {
+            gm_store<A_KC, NA, BM>(ra, As0 + buf * A_FLOATS, tid);
+            gm_store<B_KC, NB, BN>(rb, Bs0 + buf * B_FLOATS, tid);
+        };
+        auto compute = [&](int buf) {
+            const float* As = As0 + buf * A_FLOATS;
+            const float* Bs = Bs0 + buf * B_FLOATS;
+            f32x4 af0[WM], bf0[WN], af1[WM], bf1[WN];
+            read_frags(As, Bs, 0, af0, bf0);
+            read_frags(As, Bs, 1, af1, bf1);
+            mfma_group(af0, bf0);
+            read_frags(As, Bs, 2, af0, bf0);
+            mfma_group(af1, bf1);
+            read_frags(As, Bs, 3, af1, bf1);
+            mfma_group(af0, bf0);
+            mfma_group(af1, bf1);
+        };
+        const int nsteps = (K - kb + GM_BK - 1) / GM_BK;
+        load(kb);
+        store(0);
+        if (nsteps > 1) load(kb + GM_BK);
         __syncthreads();
-        cur ^= 1;
-    }
+        int cur = 0, step = 0;
+        for (; step + 2 < nsteps; ++step) {           // steady state, branch-free
+            store(cur ^ 1);                            // step+1: registers -> the other LDS buffer
+            load(kb + (step + 2) * GM_BK);             // step+2: global -> registers
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+        for (; step < nsteps; ++step) {                // last two steps
+            if (step + 1 < nsteps) store(cur ^ 1);
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    const bool full = a_vec && b_vec && m0 + BM <= M && n0 + BN <= N && ((K - kb) % GM_BK == 0);
+    if (full) run(std::true_type{});
+    else run(std::false_type{});
 
 #pragma unroll
     for (int t = 0; t < WM; ++t)

@@ -303,11 +303,22 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                                 const float* x, const float* dlogits, void* workspace, uint64_t seed,
                                 const uint64_t* seed_dev, int stage_begin, int stage_end, void* stream, void* aux_stream) {
     SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward: null pointer");
-    // cross-stream ordering (host objects, created once): ev_dg[l] = data gradient of block l complete (main stream),
-    // ev_bn[l] = BatchNorm backward of block l complete (auxiliary stream)
-    static hipEvent_t ev_dg[SED_MAX_CONV] = {}, ev_bn[SED_MAX_CONV] = {};
+    // cross-stream ordering: ev_dg[l] = data gradient of block l complete (main stream), ev_bn[l] = BatchNorm backward of
+    // block l complete (auxiliary stream).  Host objects created on first use, one set per calling thread and device,
+    // so concurrent callers (other threads, other devices) never share an event.
+    constexpr int kMaxDev = 16;
+    static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
+    hipEvent_t* ev_dg = nullptr;
+    hipEvent_t* ev_bn = nullptr;
     if (s_aux && s_aux != s_main) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
+            sed_set_error("net_backward: device index %d outside [0,%d)", dev, kMaxDev);
+            return SED_EINVAL;
+        }
+        ev_dg = ev_all[dev][0];
+        ev_bn = ev_all[dev][1];
         for (int l = 0; l < SED_MAX_CONV; ++l)
             if (!ev_dg[l]) {
                 if (hipEventCreateWithFlags(&ev_dg[l], hipEventDisableTiming) != hipSuccess ||

@@ -4,7 +4,6 @@ Same signature and return types; what changes is where time goes: losses and pre
 accumulated on the device and copied to the host ONCE per epoch instead of ``loss.item()`` and
 ``.cpu().numpy()`` every step (sed.py:138-139), and validation runs without building autograd graphs.
 """
-import numpy as np
 import torch
 
 from . import metrics, ops
