@@ -79,6 +79,7 @@ __global__ __launch_bounds__(1024) void bn_stat_sums_k(const float* __restrict__
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, q = 0.0;
     if (c < C)
+#pragma unroll 8                                  // independent loads in flight: the partials sit in another XCD's L2
         for (int r = sl; r < rows; r += 32) {
             a += (double)part[(size_t)r * 2 * C + c];
             q += (double)part[(size_t)r * 2 * C + C + c];
@@ -443,6 +444,7 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int 
     const int c = blockIdx.x * 32 + cl;
     double a = 0.0, q = 0.0;
     if (c < C)
+#pragma unroll 8                                  // independent loads in flight: the partials sit in another XCD's L2
         for (int r = sl; r < rows; r += 32) {
             a += (double)part[(size_t)r * 2 * C + c];
             q += (double)part[(size_t)r * 2 * C + C + c];

@@ -667,6 +667,7 @@ __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float*
     if (i >= n) return;
     int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cin * Cout);
     float a = 0.f;
+#pragma unroll 8
     for (int g = 0; g < ngroups; ++g) a += slabs[(size_t)g * n + i];
     dw[((size_t)co * Cin + ci) * 9 + tap] = a;
 }

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(1024) void conv1_wgrad_reduce_k(const float* __rest
     const int i = blockIdx.x * 32 + cl;
     double a = 0.0;
     if (i < n)
+#pragma unroll 8
         for (int r = sl; r < rows; r += 32) a += (double)part[(size_t)r * n + i];
     s1[sl][cl] = a;
     __syncthreads();

@@ -252,6 +252,7 @@ __global__ void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits
     long n = (long)M * N;
     if (i >= n) return;
     float a = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) a += slabs[(size_t)z * n + i];
     C[(i / N) * ldc + (i % N)] = a;
 }
@@ -403,6 +404,7 @@ __global__ void linear_dw_reduce_k(const float* __restrict__ part, int chunks, i
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tot) return;
     double a = 0.0;
+#pragma unroll 8
     for (int c = 0; c < chunks; ++c) a += (double)part[(size_t)c * tot + i];
     if (i < NK) dW[i] = (float)a;
     else if (db) db[i - NK] = (float)a;

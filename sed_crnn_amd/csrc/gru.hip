@@ -243,6 +243,7 @@ __global__ void gru_bias_grad_k(const float* __restrict__ bpart, int nblk, int H
     if (i >= 2 * 4 * H) return;
     int j = i % H, c = (i / H) % 4, dir = i / (4 * H);
     float a = 0.f;
+#pragma unroll 8
     for (int b = 0; b < nblk; ++b) a += bpart[((size_t)(b * 2 + dir) * 4 + c) * H + j];
     float* dbih = dir ? dbih1 : dbih0;
     float* dbhh = dir ? dbhh1 : dbhh0;
