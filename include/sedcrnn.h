@@ -280,15 +280,20 @@ int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float
  * Stages let the host overlap the gradient all-reduce with the rest of backward:
  *   stage 0 = dense head + GRU stack, stage s>=1 = conv block l = n_conv - s.  Run stages
  *   [stage_begin, stage_end) in increasing order; (0, n_conv+1) = everything.
- * When stage s returns, every gradient of that stage (block l: conv weight/bias, BatchNorm gamma/beta) is complete on
- * `stream`.
- * aux_stream (NULL or == stream: serial): a second hipStream_t.  The stage of block l then issues the HBM-bound
- * BatchNorm/ReLU/pool backward of block l-1 (for a fused first block: all of block 0) on it, beside block l's
- * MFMA-bound weight gradient on `stream`; the stage of block l-1 starts by waiting for it (hipEvents).  Stages must
- * therefore be run in order with the same aux_stream for the whole backward. */
+ * The critical chain of the conv backward is dgrad(top) -> BN(top-1) -> ... -> dgrad(1) -> BN(0); the weight gradients
+ * hang off it and are deferred to the stage of block 1, where all of them run back to back.  Hence the gradients of
+ * stage 0 are complete on `stream` when stage 0 returns, and those of conv block l when stage
+ * sed_net_backward_ready_stage(cfg, l) returns (block 0: the last stage; every other block: the stage of block 1).
+ * aux_stream (NULL or == stream: serial): a second hipStream_t for the HBM-bound BatchNorm/ReLU/pool backward passes
+ * that have MFMA-bound work to hide behind: BN(top) beside the GRU weight-gradient GEMM (issued by stage 0), BN(0) (for
+ * a fused first block: all of block 0) beside the conv weight gradients (issued by the stage of block 1); hipEvents
+ * order the two streams and every auxiliary launch is joined back into `stream` before the last stage returns.
+ * Stages must therefore be run in order with the same aux_stream for the whole backward. */
 int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,
                      const float* x, const float* dlogits, void* workspace, uint64_t seed, const uint64_t* seed_dev,
                      int stage_begin, int stage_end, void* stream, void* aux_stream);
+/* Stage of sed_net_backward after which every gradient of conv block `block` is complete (<0: bad arguments). */
+int sed_net_backward_ready_stage(const sed_net_cfg* cfg, int block);
 
 /* Phased execution, for synchronised BatchNorm in data-parallel training: the per-block statistics
  * are the only cross-sample coupling besides the loss mean, so the plan can stop at them.

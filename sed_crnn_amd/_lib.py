@@ -103,6 +103,7 @@ SIGNATURES = {
     "sed_net_forward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _i, _i, _f, _stream]),
     "sed_net_backward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _f, _stream]),
     "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _fp, _i, _i, _stream, _stream]),
+    "sed_net_backward_ready_stage": (_i, [C.POINTER(NetCfg), _i]),
 }
 
 _lib = None

@@ -151,11 +151,14 @@ extern "C" int sed_bn_finalize_eval(const float* gamma, const float* beta, const
 }
 
 // out[c] = sum_r part[r*row_stride + c]
-__global__ __launch_bounds__(1024) void reduce_rows_k(const float* __restrict__ part, int rows, int C,
-                                                      int row_stride, float* __restrict__ out) {
-    __shared__ double s1[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+// 256-thread workgroups (8 channels x 32 row slices) here and in the other finalisation kernels below: they run on the
+// auxiliary stream beside a weight-gradient kernel that leaves every CU only ~80 VGPRs per SIMD lane and ~45 KB of LDS,
+// where a 1024-thread workgroup cannot be placed at all and would wait for the whole MFMA kernel to drain.
+__global__ __launch_bounds__(256) void reduce_rows_k(const float* __restrict__ part, int rows, int C,
+                                                     int row_stride, float* __restrict__ out) {
+    __shared__ double s1[32][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0;
     if (c < C) {
         double a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(1024) void reduce_rows_k(const float* __restrict__ 
 
 extern "C" int sed_reduce_rows(const float* part, int rows, int C, int row_stride, float* out, void* stream) {
     SED_REQUIRE(part && out && rows > 0 && C > 0 && row_stride >= C, "reduce_rows: bad arguments");
-    reduce_rows_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(part, rows, C, row_stride, out);
+    reduce_rows_k<<<cdiv(C, 8), 256, 0, as_stream(stream)>>>(part, rows, C, row_stride, out);
     SED_LAUNCH_CHECK("reduce_rows");
     return 0;
 }
@@ -437,11 +440,11 @@ extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dou
     return 0;
 }
 
-__global__ void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, float* sum_g, float* sum_gx,
-                                  float* dgamma, float* dbeta) {
-    __shared__ double s1[32][33], s2[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, float* sum_g,
+                                                         float* sum_gx, float* dgamma, float* dbeta) {
+    __shared__ double s1[32][9], s2[32][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, q = 0.0;
     if (c < C)
 #pragma unroll 8                                  // independent loads in flight: the partials sit in another XCD's L2
@@ -465,7 +468,7 @@ __global__ void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int 
 extern "C" int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
                                    float* dgamma, float* dbeta, void* stream) {
     SED_REQUIRE(partials && sum_g && sum_gx && rows > 0 && C > 0, "bn_bwd_finalize: bad arguments");
-    bn_bwd_finalize_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta);
+    bn_bwd_finalize_k<<<cdiv(C, 8), 256, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta);
     SED_LAUNCH_CHECK("bn_bwd_finalize");
     return 0;
 }

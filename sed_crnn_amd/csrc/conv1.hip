@@ -204,12 +204,13 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
 }
 
 // dW[co][ci][tap] = sum_r part[r][1 + tap*Cin + ci][co]   (row 0 of each block is the bias gradient)
-__global__ __launch_bounds__(1024) void conv1_wgrad_reduce_k(const float* __restrict__ part, int rows, int Cin, int C,
-                                                             float* __restrict__ dw, float* __restrict__ db) {
-    __shared__ double s1[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+// (256-thread workgroups: it runs on the auxiliary stream beside the conv weight gradients, see reduce_rows_k)
+__global__ __launch_bounds__(256) void conv1_wgrad_reduce_k(const float* __restrict__ part, int rows, int Cin, int C,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double s1[32][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
     const int NV = 1 + 9 * Cin, n = NV * C;
-    const int i = blockIdx.x * 32 + cl;
+    const int i = blockIdx.x * 8 + cl;
     double a = 0.0;
     if (i < n)
 #pragma unroll 8
@@ -324,7 +325,7 @@ extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const 
     c1_launch<3>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, nullptr, (float*)workspace, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_bwd_apply_wgrad");
     int rows = sed_conv1_fused_rows(B, T), n = (1 + 9 * Cin) * C;
-    conv1_wgrad_reduce_k<<<cdiv(n, 32), 1024, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias);
+    conv1_wgrad_reduce_k<<<cdiv(n, 8), 256, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias);
     SED_LAUNCH_CHECK("conv1_wgrad_reduce");
     return 0;
 }

@@ -303,9 +303,9 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                                 const float* x, const float* dlogits, void* workspace, uint64_t seed,
                                 const uint64_t* seed_dev, int stage_begin, int stage_end, void* stream, void* aux_stream) {
     SED_REQUIRE(p && g && x && dlogits && workspace, "net_backward: null pointer");
-    // cross-stream ordering: ev_dg[l] = data gradient of block l complete (main stream), ev_bn[l] = BatchNorm backward of
-    // block l complete (auxiliary stream).  Host objects created on first use, one set per calling thread and device,
-    // so concurrent callers (other threads, other devices) never share an event.
+    // cross-stream ordering: ev_dg[l] = the input of block l's BatchNorm backward (the gradient of its pooled output) is
+    // complete on the main stream, ev_bn[l] = BatchNorm backward of block l complete (auxiliary stream).  Host objects
+    // created on first use, one set per calling thread and device, so concurrent callers never share an event.
     constexpr int kMaxDev = 16;
     static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
@@ -368,41 +368,79 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                                         g->gru_whh[i][d], H, 3 * H, H, M, ws + L.gemm_ws, stream));
             const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
                                g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
-            if (fused) {                     // both directions at once: dW_ih = dgi^T x (M = 6H), dx = dgi W_ih (K = 6H)
-                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
+            // data gradient first: for layer 0 it is the input of the top conv block's BatchNorm backward, which then runs
+            // on the auxiliary stream beside the (independent, MFMA-bound) weight-gradient GEMM
+            if (fused) {                     // both directions at once: dx = dgi W_ih (K = 6H), dW_ih = dgi^T x (M = 6H)
                 SED_TRY(sed_gemm_f32(dgi, 6 * H, 1, p->gru_wih[i][0], K, 1, dxin, K, nullptr, 0.f, M, K, 6 * H, stream));
             } else {
-                for (int d = 0; d < 2; ++d) {
-                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
+                for (int d = 0; d < 2; ++d)
                     SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 6 * H, 1, p->gru_wih[i][d], K, 1, dxin, K, nullptr, d ? 1.f : 0.f,
                                          M, K, 3 * H, stream));
-                }
+            }
+            if (i == 0 && s_aux) {
+                const int top = L.n_conv - 1;
+                (void)hipEventRecord(ev_dg[top], s_main);
+                (void)hipStreamWaitEvent(s_aux, ev_dg[top], 0);
+                SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, top, 3, 1.f, aux_stream));
+                (void)hipEventRecord(ev_bn[top], s_aux);
+            }
+            if (fused) {
+                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
+            } else {
+                for (int d = 0; d < 2; ++d)
+                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
             }
         }
     }
     // ── conv blocks, last to first ──
+    // Critical chain: dgrad(top) -> BN(top-1) -> dgrad(top-1) -> ... -> dgrad(1) -> BN(0).  The weight gradients hang off
+    // it, so they are deferred: stage of block l >= 1 = [BN(l) if not done yet] dgrad(l), BN(l-1); the stage of block 1
+    // then issues BN(0) on the auxiliary stream and, beside it on the main stream, the weight gradients of ALL blocks
+    // >= 1 (MFMA-bound, ~2.4 ms at config 2: the window BN(0) needs at the low occupancy the weight-gradient kernel
+    // leaves it).  BN of blocks 1..top-1 runs alone on the main stream (co-running it with a weight gradient stretched
+    // it to the whole window and hid nothing); BN(top) was issued by stage 0 beside the GRU weight-gradient GEMM.
     auto bn_passes = [&](int l, void* st) -> int { return bn_backward(L, c, p, g, x, ws, seed, seed_dev, l, 3, 1.f, st); };
+    auto wgrad = [&](int l) -> int {
+        const ConvL& q = L.cv[l];
+        const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
+        return sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream);
+    };
+    const int top = L.n_conv - 1;
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
-        // With an auxiliary stream the HBM-bound BN backward of block l was issued there by the stage of block l+1,
-        // beside that block's MFMA-bound weight gradient; the top block (and the serial mode) runs it here.
-        if (s_aux && l < L.n_conv - 1) (void)hipStreamWaitEvent(s_main, ev_bn[l], 0);
-        else SED_TRY(bn_passes(l, stream));
-        if (q.fused) continue;                       // block 0 fused: bn_passes already produced every gradient
-        if (l > 0) {   // data gradient = the same convolution with flipped, transposed taps
-            SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
-            if (s_aux) {
-                (void)hipEventRecord(ev_dg[l], s_main);
-                (void)hipStreamWaitEvent(s_aux, ev_dg[l], 0);
-                SED_TRY(bn_passes(l - 1, aux_stream));
-                (void)hipEventRecord(ev_bn[l - 1], s_aux);
-            }
+        if (l == top) {                              // BN(top): on the auxiliary stream since stage 0, or here
+            if (s_aux) (void)hipStreamWaitEvent(s_main, ev_bn[top], 0);
+            else SED_TRY(bn_passes(top, stream));
+        } else if (l == 0 && s_aux) {
+            (void)hipStreamWaitEvent(s_main, ev_bn[0], 0);
         }
-        const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
-        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
+        if (l == 0) {
+            if (!q.fused) SED_TRY(wgrad(0));         // fused block 0: its BN pass already produced every gradient
+            continue;
+        }
+        // data gradient = the same convolution with flipped, transposed taps
+        SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+        if (l > 1) {
+            SED_TRY(bn_passes(l - 1, stream));
+            continue;
+        }
+        if (s_aux) {
+            (void)hipEventRecord(ev_dg[0], s_main);
+            (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
+            SED_TRY(bn_passes(0, aux_stream));
+            (void)hipEventRecord(ev_bn[0], s_aux);
+        } else {
+            SED_TRY(bn_passes(0, stream));
+        }
+        for (int k = top; k >= 1; --k) SED_TRY(wgrad(k));
     }
     return 0;
+}
+
+extern "C" int sed_net_backward_ready_stage(const sed_net_cfg* c, int block) {
+    if (!c || block < 0 || block >= c->n_conv) { sed_set_error("net_backward_ready_stage: bad arguments"); return SED_EINVAL; }
+    return block == 0 ? c->n_conv : c->n_conv - 1;
 }
 
 extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,

@@ -222,9 +222,18 @@ class HipCRNN(nn.Module):
         return self._arena_grad
 
     def bucket_slices(self):
-        """Arena slices in backward-completion order, one per backward stage."""
-        b = [0] + self._stage_ends
-        return [(b[i], b[i + 1]) for i in range(len(b) - 1)]
+        """One arena slice per backward stage: the gradients that are complete when that stage returns (empty for a stage
+        that completes none).  Stage 0 = head + GRU; the conv weight gradients are deferred to the stage of block 1
+        (``sed_net_backward_ready_stage``), so the slices of blocks >= 1 merge into that stage's slice."""
+        b = [0] + self._stage_ends                   # arena order: head+GRU, then conv blocks top -> 0
+        n = len(self.conv_channels)
+        cfg = self._cfg(1, self.time_factor)
+        ready = [lib().sed_net_backward_ready_stage(C.byref(cfg), n - s) for s in range(1, n + 1)]   # per arena stage s
+        out = [(b[0], b[1])]
+        for st in range(1, n + 1):
+            mine = [s for s in range(1, n + 1) if ready[s - 1] == st]
+            out.append((b[mine[0]], b[mine[-1] + 1]) if mine else (b[st], b[st]))
+        return out
 
     def bind_flat_grads(self):
         """Point every p.grad at its arena view (what the fused optimiser / all-reduce operate on)."""
