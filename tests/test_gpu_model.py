@@ -468,3 +468,39 @@ def test_dropout_active_parity_with_injected_masks(sed):
     rg = dict(ref.named_parameters())
     for k, q in m.named_parameters():
         _cmp(q.grad, rg[k].grad, atol=1e-4, rtol=1e-2, msg=k)
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("cin,C", [(1, 32), (4, 32)])
+def test_staged_backward_completes_each_bucket_slice_when_its_stage_returns(sed, overlap, cin, C):
+    """the contract the gradient all-reduce relies on: after stage s of sed_net_backward has been waited for on the main
+    stream, the arena slice bucket_slices()[s] already holds its final values (with and without the auxiliary stream,
+    fused and stored first block); together the slices cover the whole arena"""
+    from oracle import crnn_ref
+    from sed_crnn_amd import ops
+    torch.manual_seed(13)
+    m = sed.TimePooledCRNN(conv_channels=C, dropout=0.5, in_channels=cin, gru_hidden=16).cuda()
+    m.overlap_wgrad = overlap
+    x, y = crnn_ref.synthetic_batch(6, cin, 40, 32, 4, seed=4)
+    x, y = x.cuda(), y.cuda()
+    m.train()
+    logits = m._run_forward(x, training=True)
+    _, dlogits, _ = ops.loss_fwd_bwd(logits, y, "bce", 0.25, 2.0, "mean")
+    m._run_backward(x, dlogits)                               # reference: the whole backward at once
+    torch.cuda.synchronize()
+    want = m.flat_grads().clone()
+    slices = m.bucket_slices()
+    assert slices[0][0] == 0 and slices[-1][1] == want.numel()
+    assert all(a <= b for a, b in slices) and all(slices[i][1] == slices[i + 1][0] or slices[i + 1][0] == slices[i + 1][1]
+                                                  for i in range(len(slices) - 1))
+    valid = torch.zeros(want.numel(), dtype=torch.bool, device="cuda")      # the arena pads every tensor to 4 floats
+    for p_, o in zip(m._arena_params, m._arena_offsets):
+        valid[o:o + p_.numel()] = True
+    m.flat_grads().fill_(float("nan"))
+    for s, (a, b) in enumerate(slices):
+        m._run_backward(x, dlogits, s, s + 1)
+        torch.cuda.current_stream().synchronize()             # what an all-reduce enqueued on this stream would see
+        got = m.flat_grads()[a:b].clone()
+        assert torch.equal(got[valid[a:b]], want[a:b][valid[a:b]]), f"stage {s}: slice [{a},{b}) incomplete or different"
+    torch.cuda.synchronize()
+    assert torch.equal(m.flat_grads()[valid], want[valid])
