@@ -303,7 +303,9 @@ extern "C" int sed_bn_bwd_rows(int B, int T, int pool_t) {
 
 // MODE 0: reduce (partials [grid][2][C] of sum g, sum g*xhat)
 // MODE 1: apply  (dy, and dbias partials [grid][C])
-template <int MODE>
+// P12: the pool is (1,2) (the time-pooled topology of the reference): the window loops unroll, both conv outputs of a
+// window are loaded together and kept for the apply loop instead of being read twice.
+template <int MODE, bool P12>
 __global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
     const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -365,9 +367,17 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
             f32x4 bx = {0, 0, 0, 0};
             int bidx[4] = {0, 0, 0, 0};
             int widx = 0;
-            for (int df = 0; df < pf; ++df)               // window order = (f, t): row-major over (H=F, W=T)
-                for (int dt = 0; dt < pt; ++dt, ++widx) {
-                    f32x4 v = *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
+            f32x4 vw[2];
+            if (P12) {
+                const float* yp = y + (((b * T + tp * 2) * F + fp) * (size_t)C) + c4 * 4;
+                vw[0] = *(const f32x4*)yp;
+                vw[1] = *(const f32x4*)(yp + (size_t)F * C);
+            }
+#pragma unroll
+            for (int df = 0; df < (P12 ? 1 : pf); ++df)   // window order = (f, t): row-major over (H=F, W=T)
+#pragma unroll
+                for (int dt = 0; dt < (P12 ? 2 : pt); ++dt, ++widx) {
+                    f32x4 v = P12 ? vw[dt] : *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
                     f32x4 z = v * sc + sh;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -381,10 +391,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
                 a2 += g * bx;
             } else {
                 widx = 0;
-                for (int df = 0; df < pf; ++df)
-                    for (int dt = 0; dt < pt; ++dt, ++widx) {
+#pragma unroll
+                for (int df = 0; df < (P12 ? 1 : pf); ++df)
+#pragma unroll
+                    for (int dt = 0; dt < (P12 ? 2 : pt); ++dt, ++widx) {
                         size_t off = (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4;
-                        f32x4 v = *(const f32x4*)(y + off);
+                        f32x4 v = P12 ? vw[dt] : *(const f32x4*)(y + off);
                         f32x4 o;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -431,11 +443,19 @@ extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dou
     SED_REQUIRE(C / 4 <= 256, "bn_bwd_reduce: C=%d too large (max 1024)", C);
     size_t lds = bwd_lds(F, C, pf, out_tcf);
     SED_REQUIRE(lds <= 150 * 1024, "bn_bwd_reduce: tile too large for LDS");
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool p12 = (pf == 1 && pt == 2);
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     int grid = sed_bn_bwd_rows(B, T, pt);
     SedProfScope prof(SED_K_BN_BWD_REDUCE, as_stream(stream), 4.0 * B * C * ((double)T * F + (double)(T / pt) * (F / pf)));
-    bn_relu_pool_drop_bwd_k<0><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, nullptr, nullptr,
-                                                                       nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
+    if (p12)
+        bn_relu_pool_drop_bwd_k<0, true><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, nullptr, nullptr,
+                                                                                 nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
+    else
+        bn_relu_pool_drop_bwd_k<0, false><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, nullptr, nullptr,
+                                                                                  nullptr, partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
     SED_LAUNCH_CHECK("bn_bwd_reduce");
     return 0;
 }
@@ -485,11 +505,19 @@ extern "C" int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout
     SED_REQUIRE(C / 4 <= 256, "bn_bwd_apply: C=%d too large (max 1024)", C);
     size_t lds = bwd_lds(F, C, pf, out_tcf);
     SED_REQUIRE(lds <= 150 * 1024, "bn_bwd_apply: tile too large for LDS");
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const bool p12 = (pf == 1 && pt == 2);
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)bn_relu_pool_drop_bwd_k<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     int grid = sed_bn_bwd_rows(B, T, pt);
     SedProfScope prof(SED_K_BN_BWD_APPLY, as_stream(stream), 4.0 * B * C * (2.0 * T * F + (double)(T / pt) * (F / pf)));
-    bn_relu_pool_drop_bwd_k<1><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, sum_g, sum_gx, dy,
-                                                                       dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
+    if (p12)
+        bn_relu_pool_drop_bwd_k<1, true><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, sum_g, sum_gx, dy,
+                                                                                 dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
+    else
+        bn_relu_pool_drop_bwd_k<1, false><<<grid, 256, lds, as_stream(stream)>>>(y, dout, scale, shift, mean, rstd, sum_g, sum_gx, dy,
+                                                                                  dbias_partials, B, T, F, C, pf, pt, out_tcf, drop_p, seed, seed_dev);
     SED_LAUNCH_CHECK("bn_bwd_apply");
     return 0;
 }
