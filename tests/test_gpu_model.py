@@ -504,3 +504,47 @@ def test_staged_backward_completes_each_bucket_slice_when_its_stage_returns(sed,
         assert torch.equal(got[valid[a:b]], want[a:b][valid[a:b]]), f"stage {s}: slice [{a},{b}) incomplete or different"
     torch.cuda.synchronize()
     assert torch.equal(m.flat_grads()[valid], want[valid])
+
+
+def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
+    """learnable synthetic task (labels = a threshold on a band of the input), 40 Adam steps on 4 batches with the fused
+    trainer vs the CPU oracle's fit_step: per-step losses within 1e-3, final frame-wise probabilities within 1e-3 and
+    identical ER / F1 at 1 s (the north-star parity statement, beyond the 6 steps of golden g3)"""
+    from oracle import crnn_ref
+    from sed_crnn_amd.trainer import FusedTrainStep
+    torch.manual_seed(99)
+    kw = dict(conv_channels=16, dropout=0.0, gru_hidden=16)
+    ref = crnn_ref.SedNetRef(**kw)
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(4):
+        x = torch.randn(16, 1, 40, 64, generator=g)
+        band = x[:, 0, 8:16, :].mean(1)                                   # [B,T]
+        y = (band.reshape(16, 8, 8).amax(2) > 0.45).float().unsqueeze(-1)  # [B,T',1]: learnable, ~35 % positive
+        batches.append((x, y))
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-3)
+    step = FusedTrainStep(m, lr=2e-3, loss="bce")
+    lr_, lh_ = [], []
+    for it in range(40):
+        x, y = batches[it % 4]
+        lr_.append(float(crnn_ref.fit_step(ref, opt, x, y)[0]))
+        lh_.append(step.step(x.cuda(), y.cuda())[0])
+    lh_ = torch.stack([l.reshape(()) for l in lh_]).cpu().numpy()
+    np.testing.assert_allclose(lh_, np.asarray(lr_), atol=1e-3)
+    assert lr_[-1] < 0.8 * lr_[0]                                          # it actually learns
+    ref.eval()
+    m.eval()
+    xs = torch.cat([b[0] for b in batches])
+    ys = torch.cat([b[1] for b in batches]).numpy()
+    with torch.no_grad():
+        pr = torch.sigmoid(ref(xs)).numpy()
+        ph = torch.sigmoid(m(xs.cuda())).cpu().numpy()
+    np.testing.assert_allclose(ph, pr, atol=1e-3)
+    stable = np.abs(pr - 0.5) > 2e-3                                       # frames whose decision a 1e-3 difference cannot flip
+    assert stable.mean() > 0.95 and np.array_equal((ph > 0.5)[stable], (pr > 0.5)[stable])
+    if stable.all():
+        a, b = sed.metrics.compute_scores(ph > 0.5, ys, 5), sed.metrics.compute_scores(pr > 0.5, ys, 5)
+        assert a == b
