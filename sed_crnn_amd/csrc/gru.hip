@@ -53,8 +53,9 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
     for (int i = g; i < GRU_BT * H; i += blockDim.x) h_s[i] = 0.f;
     __syncthreads();
 
-    // input projections of a step are fetched one step ahead (an HBM miss is ~1 us: longer than a whole step)
-    float gr[GRU_BT], gz[GRU_BT], gn[GRU_BT], nr[GRU_BT], nz[GRU_BT], nn[GRU_BT];
+    // input projections of a step are fetched TWO steps ahead (a miss to HBM / another XCD's L2 is ~1-2 us, about a whole
+    // step): the copy at the end of step s then waits for loads that were issued during step s-1
+    float gr[GRU_BT], gz[GRU_BT], gn[GRU_BT], nr[GRU_BT], nz[GRU_BT], nn[GRU_BT], mr[GRU_BT], mz[GRU_BT], mn[GRU_BT];
     auto fetch_gi = [&](int s, float* a, float* bq, float* c) {
         const int tt = dir ? (T - 1 - s) : s;
 #pragma unroll
@@ -67,9 +68,10 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
         }
     };
     fetch_gi(0, gr, gz, gn);
+    fetch_gi(1, nr, nz, nn);
     for (int s = 0; s < T; ++s) {
         const int tt = dir ? (T - 1 - s) : s;
-        fetch_gi(s + 1, nr, nz, nn);
+        fetch_gi(s + 2, mr, mz, mn);
         if (row) {
             float acc[GRU_BT];
 #pragma unroll
@@ -119,7 +121,10 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
             }
         }
 #pragma unroll
-        for (int b = 0; b < GRU_BT; ++b) { gr[b] = nr[b]; gz[b] = nz[b]; gn[b] = nn[b]; }
+        for (int b = 0; b < GRU_BT; ++b) {
+            gr[b] = nr[b]; gz[b] = nz[b]; gn[b] = nn[b];
+            nr[b] = mr[b]; nz[b] = mz[b]; nn[b] = mn[b];
+        }
         __syncthreads();
     }
 }
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;   // bias-gradient partial sums over this block's rows and steps
     __syncthreads();
 
-    float cs[GRU_BT][6], ns[GRU_BT][6];          // r, z, n, gh_n, h_prev, dout of the current / next step
+    float cs[GRU_BT][6], ns[GRU_BT][6], ms[GRU_BT][6];   // r, z, n, gh_n, h_prev, dout of the current / next / next-but-one step
     auto fetch_sv = [&](int s, float (*q)[6]) {
         const int tt = dir ? s : (T - 1 - s);
 #pragma unroll
@@ -165,10 +170,14 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
             }
         }
     };
+    // two steps ahead, as in the forward kernel (one step ahead where the 1024-thread variant has no registers to spare)
+    constexpr bool AHEAD2 = !(HREG == 0 && GRU_BT == 4);
     fetch_sv(0, cs);
+    if (AHEAD2) fetch_sv(1, ns);
     for (int s = 0; s < T; ++s) {
         const int tt = dir ? s : (T - 1 - s);    // reverse of the forward processing order
-        fetch_sv(s + 1, ns);
+        if (AHEAD2) fetch_sv(s + 2, ms);
+        else fetch_sv(s + 1, ns);
         if (gate) {
 #pragma unroll
             for (int b = 0; b < GRU_BT; ++b) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
 #pragma unroll
         for (int b = 0; b < GRU_BT; ++b)
 #pragma unroll
-            for (int e = 0; e < 6; ++e) cs[b][e] = ns[b][e];
+            for (int e = 0; e < 6; ++e) { cs[b][e] = ns[b][e]; if (AHEAD2) ns[b][e] = ms[b][e]; }
         __syncthreads();
     }
     if (bpart && gate) {
