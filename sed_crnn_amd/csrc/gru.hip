@@ -106,9 +106,13 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
                 int bg = b0 + b;
                 float ghr = gh_s[b * H3 + g], ghz = gh_s[b * H3 + H + g], ghn = gh_s[b * H3 + 2 * H + g];
                 float hp = h_s[b * H + g];
-                float r = 1.f / (1.f + expf(-(gr[b] + ghr)));
-                float z = 1.f / (1.f + expf(-(gz[b] + ghz)));
-                float n = tanhf(gn[b] + r * ghn);
+                // v_exp_f32 / v_rcp_f32 forms (abs. error ~1e-7, the serial step is latency-bound): sigmoid, and
+                // tanh(a) = sign(a) (1 - e)/(1 + e) with e = exp(-2|a|), which never overflows
+                float r = __fdividef(1.f, 1.f + __expf(-(gr[b] + ghr)));
+                float z = __fdividef(1.f, 1.f + __expf(-(gz[b] + ghz)));
+                float a = gn[b] + r * ghn;
+                float e2 = __expf(-2.f * fabsf(a));
+                float n = copysignf(__fdividef(1.f - e2, 1.f + e2), a);
                 float hn = (1.f - z) * n + z * hp;
                 h_s[b * H + g] = hn;
                 if (bg < B) {
