@@ -491,6 +491,70 @@ __global__ __launch_bounds__(256) void conv3x3_small_wgrad_k(
     }
 }
 
+// small, Cin <= 4 (the first layer of the multichannel configurations): every input channel in ONE pass over dY
+// (the generic kernel above re-reads dY once per input channel), 9*CIN float4 accumulators per thread.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_c_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    const int hn = (TT + 2) * F2 * CIN;
+    float* hp = smem;                               // [(TT+2)][F2][CIN]
+    float* red = smem + ((hn + 3) & ~3);            // [nslots][9][Cout]
+    const int tid = threadIdx.x;
+    const int ncg = Cout >> 2, nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    f32x4 acc[9 * CIN];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k) acc[k] = (f32x4){0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+        __syncthreads();
+        for (int i = tid; i < hn; i += 256) {
+            int tt, ff, ci;
+            if (x_nchw) { tt = i % (TT + 2); ff = (i / (TT + 2)) % F2; ci = i / ((TT + 2) * F2); }
+            else { ci = i % CIN; ff = (i / CIN) % F2; tt = i / (CIN * F2); }
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F)
+                v = x_nchw ? x[(((size_t)b * CIN + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * CIN + ci];
+            hp[(tt * F2 + ff) * CIN + ci] = v;
+        }
+        __syncthreads();
+        if (active) {
+            for (int p = slot; p < TT * F; p += nslots) {
+                int tl = p / F, f = p - tl * F;
+                if (t0 + tl >= T) break;
+                f32x4 d4 = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float* q = hp + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc[(kh * 3 + kw) * CIN + ci] += q[ci] * d4;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *(f32x4*)(red + (slot * 9 + k) * Cout + cg * 4) = acc[k * CIN + ci];
+        }
+        __syncthreads();
+        for (int i = tid; i < 9 * Cout; i += 256) {
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[s * 9 * Cout + i];
+            slabs[(((size_t)blockIdx.x * CIN + ci) * 9) * Cout + i] = a;
+        }
+    }
+}
+
 // small reduce: dw[co][ci][tap] = sum_g slabs[g][ci][tap][co]; block = 32 outputs x 32 group slices
 __global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                    int ngroups, int Cin, int Cout) {
@@ -696,8 +760,20 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     } else {
         SED_REQUIRE(256 % (Cout / 4) == 0 || Cout / 4 <= 256, "conv3x3_wgrad: unsupported Cout=%d", Cout);
-        SED_TRY(set_lds(conv3x3_small_wgrad_k, p.lds));
-        conv3x3_small_wgrad_k<<<p.ngroups, 256, p.lds, s>>>(x, x_is_nchw, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        const size_t lds_c = ((((size_t)(p.TT + 2) * (F + 2) * Cin + 3) & ~(size_t)3) + (size_t)256 * 36) * sizeof(float);
+        if (Cin == 2 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<2>, lds_c));
+            conv3x3_small_wgrad_c_k<2><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else if (Cin == 3 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<3>, lds_c));
+            conv3x3_small_wgrad_c_k<3><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else if (Cin == 4 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<4>, lds_c));
+            conv3x3_small_wgrad_c_k<4><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_small_wgrad_k, p.lds));
+            conv3x3_small_wgrad_k<<<p.ngroups, 256, p.lds, s>>>(x, x_is_nchw, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        }
         SED_LAUNCH_CHECK("conv3x3_small_wgrad");
         conv_wgrad_reduce_small_k<<<cdiv(n, 32), 1024, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     }

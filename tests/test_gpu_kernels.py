@@ -26,6 +26,7 @@ def close(a, b, atol, rtol=1e-4, msg=""):
 
 CONV_CASES = [  # B, Cin, F, T, Cout, nchw
     (2, 1, 40, 16, 8, True), (3, 1, 40, 18, 128, True), (2, 2, 40, 8, 128, True), (2, 4, 128, 8, 128, True),
+    (2, 3, 40, 9, 16, True), (1, 4, 40, 6, 32, False),
     (2, 8, 40, 8, 8, False), (2, 16, 40, 10, 16, False),
     (2, 128, 40, 12, 128, False), (1, 128, 40, 7, 128, False), (2, 32, 40, 8, 32, False), (2, 64, 20, 8, 64, False),
     (1, 128, 128, 4, 128, False), (2, 128, 40, 8, 256, False), (2, 128, 128, 3, 128, False),
