@@ -196,6 +196,83 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
     }
 }
 
+// small, Cin <= 4: the 9*CIN weight float4 of a thread's four output channels live in registers (the generic kernel
+// reads them from LDS for every FMA group, which bounds it at ~1.7 TB/s of output at Cin = 4); LDS holds the halo only.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_fwd_c_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, int TT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                       // [TT+2][F+2][CIN]; reused as [2][nslots][Cout] for the statistics
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int F2 = F + 2;
+    const int ncg = Cout >> 2;
+    const int nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+
+    f32x4 w[9 * CIN];
+    f32x4 bv = {0, 0, 0, 0};
+    if (active) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[tap * CIN + ci][k] = wp[((size_t)tap * Cout + cg * 4 + k) * CIN + ci];
+        if (bias) bv = *(const f32x4*)(bias + cg * 4);
+    }
+    const int hn = (TT + 2) * F2 * CIN;
+    for (int i = tid; i < hn; i += 256) {
+        int tt, ff, ci;
+        if (x_nchw) { tt = i % (TT + 2); ff = (i / (TT + 2)) % F2; ci = i / ((TT + 2) * F2); }   // time contiguous in NCHW
+        else { ci = i % CIN; ff = (i / CIN) % F2; tt = i / (CIN * F2); }
+        int t = t0 + tt - 1, f = ff - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F)
+            v = x_nchw ? x[(((size_t)b * CIN + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * CIN + ci];
+        halo[(tt * F2 + ff) * CIN + ci] = v;
+    }
+    __syncthreads();
+
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (active) {
+        for (int p = slot; p < TT * F; p += nslots) {
+            int tl = p / F, f = p - tl * F;
+            if (t0 + tl >= T) break;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc += hp[ci] * w[(kh * 3 + kw) * CIN + ci];
+                }
+            *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4) = acc;
+            s1 += acc;
+            s2 += acc * acc;
+        }
+    }
+    if (stat) {
+        __syncthreads();
+        float* red = smem;                     // [2][nslots][Cout]
+        if (active) {
+            *(f32x4*)(red + (slot)*Cout + cg * 4) = s1;
+            *(f32x4*)(red + (nslots + slot) * Cout + cg * 4) = s2;
+        }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * Cout; i += 256) {
+            int which = i / Cout, co = i - which * Cout;
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * Cout + co];
+            stat[row * 2 * Cout + i] = a;
+        }
+    }
+}
+
 // ───────────────────────── MFMA implicit-GEMM forward ─────────────────────────
 // grid (ceil(T/TT) * nft, B, Cout/(32*NCT)); 256 threads = 4 waves; block tile = TT time rows x FT mel columns.
 // wave w: co tile ct = w % NCT, row part mp = w / NCT; row tiles mt = mp + i*(4/NCT).
@@ -374,7 +451,17 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
     const double npos = (double)B * T * F;
     SedProfScope prof(p.kind == 0 ? SED_K_CONV_SMALL_FWD : SED_K_CONV_MFMA_FWD, s,
                       p.kind == 0 ? 4.0 * npos * (Cin + Cout) : 2.0 * 9.0 * Cin * Cout * npos);
-    if (p.kind == 0) {
+    if (p.kind == 0 && Cin <= 4) {
+        size_t lds = (size_t)(p.TT + 2) * (F + 2) * Cin * sizeof(float), red = (size_t)2 * 256 * 4 * sizeof(float);
+        if (lds < red) lds = red;
+        dim3 grid(p.tblocks, B);
+        switch (Cin) {
+            case 1: conv3x3_small_fwd_c_k<1><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            case 2: conv3x3_small_fwd_c_k<2><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            case 3: conv3x3_small_fwd_c_k<3><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            default: conv3x3_small_fwd_c_k<4><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+        }
+    } else if (p.kind == 0) {
         SED_TRY(set_lds(conv3x3_small_fwd_k, p.lds));
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
