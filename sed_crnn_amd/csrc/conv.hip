@@ -18,9 +18,9 @@
 #define CV_CIC 32   // input channels per LDS chunk
 #define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
 #define CV_MTW 5    // max 32-row tiles per wave
-#define WG_FT 40     // wgrad: max mel columns per tile (4 time rows)
-#define WG_NX 8      // wgrad: float4 per thread of the halo tile   (6*(WG_FT+2)*8 <= 256*WG_NX)
-#define WG_ND 20     // wgrad: float4 per thread of the dY tile     (4*WG_FT*32    <= 256*WG_ND)
+#define WG_FT 40     // wgrad: max mel columns per tile (2 time rows)
+#define WG_NX 6      // wgrad: DMA items (float4) per thread of the halo tile   (4*(WG_FT+2)*8 <= 256*WG_NX)
+#define WG_ND 10     // wgrad: DMA items (float4) per thread of the dY tile     (2*WG_FT*32    <= 256*WG_ND)
 
 #define CV_TPAD 56   // fwd: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
 #define CV_NH 8      // fwd: max float4 per thread of the halo tile ((TT+2)*(FT+2)*8 <= 256*CV_NH)
@@ -494,12 +494,12 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
     p.FT = F; p.nft = 1;
     if (p.kind == 1) {
-        // 4 time rows x (even) FT <= WG_FT mel columns: the staging register budget of the kernel (WG_NX / WG_ND)
-        p.TT = 4;
+        // 2 time rows x (even) FT <= WG_FT mel columns, two LDS buffers (the DMA item budget of the kernel: WG_NX / WG_ND)
+        p.TT = 2;
         p.nft = cdiv(F, WG_FT);
         p.FT = cdiv(F, p.nft);
         p.FT += p.FT & 1;
-        p.lds = ((size_t)6 * (p.FT + 2) * 32 + (size_t)4 * p.FT * 128) * sizeof(float);
+        p.lds = (size_t)2 * ((size_t)4 * (p.FT + 2) * 32 + (size_t)2 * p.FT * 128) * sizeof(float);
     } else {
         p.TT = 4;
         if (p.TT > T) p.TT = T;
@@ -663,22 +663,30 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* _
 }
 
 // mfma: grid (ngroups, Cin/32, Cout/128); slabs [group][9][Cin][Cout]
-// D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions.
-// A block walks tiles of TT = 4 time rows x FT mel columns.  One LDS buffer; the whole next tile is prefetched into
-// registers (WG_NX + WG_ND float4 per thread) before the MFMA loop of the current one and written to LDS after it, so
-// the staging cost is amortised over 4*FT positions (ablation: staging was 12 % of the kernel at 2-row tiles).
-// MT = false: one mel tile (FT >= F), the padding columns are fixed per block; MT = true: mel-tiled (any F),
-// the mel range test of every staged float4 depends on the tile.
+// D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions; all nine
+// taps share one dY read (9 accumulator tiles per wave); operands of k-step s+1 are read from LDS while the 9 MFMAs of
+// step s issue (explicit two-stage register pipeline, one wave per SIMD).
+// A block walks tiles of TT = 2 time rows x FT mel columns through two LDS buffers; the next tile is brought in by
+// global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no commit pass, one barrier per tile) while the MFMA loop runs on
+// the current one.  The register-staged predecessor (4-row tiles, whole next tile prefetched into 112 VGPRs) ran at the
+// same 117 TFLOP/s but held 428 VGPRs and 114 KB of LDS per CU, which kept every other kernel off the CU; this one
+// holds 251 VGPRs, so the HBM-bound BatchNorm / first-block backward passes on the auxiliary stream really run beside it.
+// MT = false: one mel tile (FT >= F); MT = true: mel-tiled (any F).
+// The LDS image is lane-linear ([position][32 ci] / [position][128 co]): float4 number i of a tile goes to byte 16*i,
+// so wave w's u-th load instruction covers items u*256 + 64*w .. +63 with a wave-uniform LDS base.
+typedef __attribute__((address_space(1))) const void* sed_gptr_t;
+typedef __attribute__((address_space(3))) void* sed_lptr_t;
+
 template <bool MT>
-__global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
+__global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
     int B, int Cin, int F, int T, int Cout, int FT, int nft, int tblocks, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TT = 4, NX = WG_NX, ND = WG_ND;
+    constexpr int TT = 2, NX = WG_NX, ND = WG_ND;
     const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
     const int MROWS = TT * FT;
-    const int XH = HR * 32;
+    const int XH = HR * 32, BUF = XH + MROWS * 128;
     const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -690,74 +698,53 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
-    f32x4 px[NX], pd[ND];
-    // tile-invariant part of the staging addresses, computed once per block: element offset from the tile origin
-    // (b, t0, f0) and where the float4 sits in the tile; per tile only a base pointer, one add and the range tests
-    // remain (the index math otherwise runs with the MFMA pipe idle).
-    //   MT = false: xt = time row (-1..4; a huge negative marks padding / out of the tile), dt = time row (huge: none)
-    //   MT = true : xt = tt | ff << 3 (halo coordinates), dt = tl | fl << 2, with ff / fl huge for "none"
+    // per-thread, tile-invariant: element offset from the tile origin (b, t0, f0) and the halo / tile coordinates
+    //   xt = tt | ff << 3 (halo coordinates; ff huge: item past the tile), dt = tl | fl << 2 (fl huge: none)
     int xo[NX], xt[NX], dofs[ND], dt[ND];
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
         int i = tid + u * 256, row = i >> 3, q = i & 7;
         int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-        if (MT) xt[u] = (i < HR * 8) ? (tt | (ff << 3)) : (1 << 24);
-        else xt[u] = (i < HR * 8 && ff >= 1 && ff <= F) ? tt - 1 : -(1 << 20);
+        xt[u] = (i < HR * 8) ? (tt | (ff << 3)) : (1 << 24);
         xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
     }
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
         int i = tid + u * 256, row = i >> 5, q = i & 31;
         int tl = sed_fdiv(row, invF), fl = row - tl * FT;
-        if (MT) dt[u] = (i < MROWS * 32) ? (tl | (fl << 2)) : (1 << 24);
-        else dt[u] = (i < MROWS * 32 && fl < F) ? tl : (1 << 20);
+        dt[u] = (i < MROWS * 32) ? (tl | (fl << 2)) : (1 << 24);
         dofs[u] = (tl * F + fl) * Cout + co0 + q * 4;
     }
-    auto fetch = [&](int tile) {          // global -> registers
+    auto issue = [&](int tile, float* buf) {          // global -> LDS (DMA); padding / out-of-range items are zeroed
         int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
-        int tb = rem / nft, f0 = (rem - tb * nft) * FT, t0 = tb * TT;
+        int tb = rem / nft, f0 = MT ? (rem - tb * nft) * FT : 0, t0 = tb * TT;
         const float* xb = x + (((size_t)b * T + t0) * F + f0) * Cin;
         const float* db = dy + (((size_t)b * T + t0) * F + f0) * Cout;
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
-            f32x4 v = {0, 0, 0, 0};
-            if (MT) {
+            const int i = tid + u * 256;
+            if (i < HR * 8) {
                 int t = t0 + (xt[u] & 7) - 1, f = f0 + (xt[u] >> 3) - 1;
-                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F) v = *(const f32x4*)(xb + xo[u]);
-            } else {
-                int t = t0 + xt[u];
-                if (t >= 0 && t < T) v = *(const f32x4*)(xb + xo[u]);
+                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F)
+                    __builtin_amdgcn_global_load_lds((sed_gptr_t)(xb + xo[u]), (sed_lptr_t)(buf + (u * 256 + wave * 64) * 4), 16, 0, 0);
+                else
+                    *(f32x4*)(buf + i * 4) = (f32x4){0, 0, 0, 0};
             }
-            px[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < ND; ++u) {
-            f32x4 v = {0, 0, 0, 0};
-            if (MT) {
-                if (t0 + (dt[u] & 3) < T && f0 + (dt[u] >> 2) < F) v = *(const f32x4*)(db + dofs[u]);
-            } else {
-                if (t0 + dt[u] < T) v = *(const f32x4*)(db + dofs[u]);
+            const int i = tid + u * 256;
+            if (i < MROWS * 32) {
+                if (t0 + (dt[u] & 3) < T && f0 + (dt[u] >> 2) < F)
+                    __builtin_amdgcn_global_load_lds((sed_gptr_t)(db + dofs[u]), (sed_lptr_t)(buf + XH + (u * 256 + wave * 64) * 4), 16, 0, 0);
+                else
+                    *(f32x4*)(buf + XH + i * 4) = (f32x4){0, 0, 0, 0};
             }
-            pd[u] = v;
-        }
-    };
-    auto commit = [&](float* buf) {       // registers -> LDS
-#pragma unroll
-        for (int u = 0; u < NX; ++u) {
-            int i = tid + u * 256;
-            if (i < HR * 8) *(f32x4*)(buf + i * 4) = px[u];
-        }
-#pragma unroll
-        for (int u = 0; u < ND; ++u) {
-            int i = tid + u * 256;
-            if (i < MROWS * 32) *(f32x4*)(buf + XH + i * 4) = pd[u];
         }
     };
     auto compute = [&](const float* buf) {
         const float* xh = buf;
         const float* dys = buf + XH;
-        // one wave per SIMD: the LDS operands of k-step fs+1 are read while the 9 MFMAs of step fs issue
-        // (explicit two-stage register pipeline; position p = tl*FT + 2*fs + h)
         const int nfs = FT >> 1;
         for (int tl = 0; tl < TT; ++tl) {
             const float* xrow = xh + (tl * F2 + h) * 32 + r;
@@ -788,18 +775,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_wgrad_k(
         }
     };
 
-    int tile = blockIdx.x;
-    if (tile < ntiles) { fetch(tile); commit(smem); }
-    __syncthreads();
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) issue(tile, smem);
+    __syncthreads();                                 // drains the DMA (vmcnt) and the zero writes
     for (; tile < ntiles; tile += gridDim.x) {
         const int nxt = tile + gridDim.x;
-        if (nxt < ntiles) fetch(nxt);
-        compute(smem);
-        __syncthreads();                       // every wave is done reading the tile
-        if (nxt < ntiles) commit(smem);
+        if (nxt < ntiles) issue(nxt, smem + (cur ^ 1) * BUF);   // that buffer was last read before the previous barrier
+        compute(smem + cur * BUF);
         __syncthreads();
+        cur ^= 1;
     }
-    // D rows = ci, cols = co
     float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
 #pragma unroll
     for (int k = 0; k < 9; ++k)

@@ -182,24 +182,32 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
         }
     }
     if (MODE == 1) return;
-    // block reduction in fixed slot order
-    __syncthreads();
-    float* red = smem;                                        // [nslots][NV][C], NV = 2 (stats / reduce) or 1 + 9*CIN
+    // block reduction in fixed slot order, NVC values per round: the apply pass runs beside the conv weight-gradient kernel,
+    // which leaves ~38 KB of LDS per CU, so its 1 + 9*CIN values go through a 20 KB buffer in rounds of 5
     constexpr int NV = (MODE == 3) ? 1 + 9 * CIN : 2;
-    if (active) {
-        *(f32x4*)(red + (slot * NV + 0) * C + cg * 4) = a1;
-        if (MODE != 3) *(f32x4*)(red + (slot * NV + 1) * C + cg * 4) = a2;
-        else {
+    constexpr int NVC = (MODE == 3) ? 5 : 2;
+    float* red = smem;                                        // [nslots][NVC][C]
 #pragma unroll
-            for (int k = 0; k < 9 * CIN; ++k) *(f32x4*)(red + (slot * NV + 1 + k) * C + cg * 4) = dw[k];
+    for (int v0 = 0; v0 < NV; v0 += NVC) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NVC; ++j) {
+                const int v = v0 + j;
+                if (v < NV) {
+                    f32x4 val = (v == 0) ? a1 : (MODE == 3 ? dw[(v - 1) < 9 * CIN ? (v - 1) : 0] : a2);
+                    *(f32x4*)(red + (slot * NVC + j) * C + cg * 4) = val;
+                }
+            }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < NV * C; i += 256) {
-        int which = i / C, c = i - which * C;
-        float a = 0.f;
-        for (int s = 0; s < nslots; ++s) a += red[(s * NV + which) * C + c];
-        partials[(size_t)blockIdx.x * NV * C + i] = a;
+        __syncthreads();
+        const int nv = (NV - v0 < NVC) ? NV - v0 : NVC;
+        for (int i = tid; i < nv * C; i += 256) {
+            int j = i / C, c = i - j * C;
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[(s * NVC + j) * C + c];
+            partials[(size_t)blockIdx.x * NV * C + (size_t)(v0 + j) * C + c] = a;
+        }
     }
 }
 
@@ -231,8 +239,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_reduce_k(const float* __restr
 
 static size_t c1_lds(int Cin, int F, int C, int mode) {
     size_t halo = (size_t)(C1_TT + 2) * (F + 2) * Cin * sizeof(float);
-    size_t nv = mode == 3 ? 1 + 9 * Cin : 2;
-    size_t red = (size_t)256 * 4 * nv * sizeof(float);        // nslots*NV*C = 256*4*NV
+    size_t nv = mode == 3 ? 5 : 2;                            // values per reduction round (NVC in the kernel)
+    size_t red = (size_t)256 * 4 * nv * sizeof(float);        // nslots*NVC*C = 256*4*NVC
     return halo > red ? halo : red;
 }
 
