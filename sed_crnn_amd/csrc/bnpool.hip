@@ -10,27 +10,28 @@
 #define BN_MAX_BLOCKS 1024
 
 // ───────────────────────── statistics ─────────────────────────
-// block = 32 channels x 32 row slices; partials [rows][2][C]
+// block = 8 channels x 128 row slices; partials [rows][2][C].  The pass is pure latency (a few MB scattered over other
+// XCDs' L2): 128 slices keep the dependent chain at rows/512 round trips (4 independent loads in flight per thread).
 __global__ __launch_bounds__(1024) void bn_finalize_train_k(
     const float* __restrict__ part, int rows, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
     float eps, float* __restrict__ mean_o, float* __restrict__ rstd_o, float* __restrict__ scale_o,
     float* __restrict__ shift_o) {
-    __shared__ double s1[32][33], s2[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double s1[128][9], s2[128][9];
+    const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, q = 0.0;
     if (c < C) {
         double a1 = 0.0, a2 = 0.0, a3 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
         int r = sl;
-        for (; r + 96 < rows; r += 128) {              // 8 independent loads in flight per thread
+        for (; r + 384 < rows; r += 512) {
             const float* p0 = part + (size_t)r * 2 * C + c;
             a += (double)p0[0];                   q += (double)p0[C];
-            a1 += (double)p0[(size_t)64 * C];     q1 += (double)p0[(size_t)64 * C + C];
-            a2 += (double)p0[(size_t)128 * C];    q2 += (double)p0[(size_t)128 * C + C];
-            a3 += (double)p0[(size_t)192 * C];    q3 += (double)p0[(size_t)192 * C + C];
+            a1 += (double)p0[(size_t)256 * C];    q1 += (double)p0[(size_t)256 * C + C];
+            a2 += (double)p0[(size_t)512 * C];    q2 += (double)p0[(size_t)512 * C + C];
+            a3 += (double)p0[(size_t)768 * C];    q3 += (double)p0[(size_t)768 * C + C];
         }
-        for (; r < rows; r += 32) {
+        for (; r < rows; r += 128) {
             a += (double)part[(size_t)r * 2 * C + c];
             q += (double)part[(size_t)r * 2 * C + C + c];
         }
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_train_k(
     __syncthreads();
     if (sl == 0 && c < C) {
         double A = 0.0, Q = 0.0;
-        for (int s = 0; s < 32; ++s) { A += s1[s][cl]; Q += s2[s][cl]; }
+        for (int s = 0; s < 128; ++s) { A += s1[s][cl]; Q += s2[s][cl]; }
         double m = A / count;
         double var = Q / count - m * m;
         if (var < 0.0) var = 0.0;
@@ -66,7 +67,7 @@ extern "C" int sed_bn_finalize_train(const float* part, int rows, int C, double 
                                      float* mean, float* rstd, float* scale, float* shift, void* stream) {
     SED_REQUIRE(part && gamma && beta && mean && rstd && scale && shift, "bn_finalize_train: null pointer");
     SED_REQUIRE(rows > 0 && C > 0 && count > 0, "bn_finalize_train: bad sizes rows=%d C=%d", rows, C);
-    bn_finalize_train_k<<<cdiv(C, 32), 1024, 0, as_stream(stream)>>>(part, rows, C, count, gamma, beta, rmean, rvar,
+    bn_finalize_train_k<<<cdiv(C, 8), 1024, 0, as_stream(stream)>>>(part, rows, C, count, gamma, beta, rmean, rvar,
                                                                       momentum, eps, mean, rstd, scale, shift);
     SED_LAUNCH_CHECK("bn_finalize_train");
     return 0;
