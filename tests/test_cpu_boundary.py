@@ -145,6 +145,30 @@ def test_mel_basis_and_logmel_oracle_properties():
     assert np.isneginf(logmel_ref.mbe(np.zeros(4096, np.float32))).all()   # log without epsilon (feature.py:59)
 
 
+def test_logmel_oracle_stft_agrees_with_scipy_and_mel_scale_anchors():
+    """librosa is absent, so the log-mel oracle stays "parity unpinned" with respect to the reference's own dependency; what
+    CAN be pinned here is its STFT half against an independent implementation (scipy.signal.stft with a periodic Hann
+    window, zero boundary padding = librosa's center=True / pad_mode='constant') and the published anchor points of the
+    Slaney mel scale (linear 200/3 Hz per mel below 1 kHz, 1 kHz = 15 mel, log spacing log(6.4)/27 above)."""
+    from scipy import signal
+    from oracle import logmel_ref
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal(1024 * 9 + 300).astype(np.float32)
+    p = logmel_ref.stft_power(y, pad_mode="constant")
+    win = signal.get_window("hann", 2048, fftbins=True)
+    np.testing.assert_allclose(win, logmel_ref.hann_periodic(2048), atol=1e-7)
+    _, _, Z = signal.stft(y.astype(np.float64), fs=44100, window=win, nperseg=2048, noverlap=1024, nfft=2048,
+                          boundary="zeros", padded=False, return_onesided=True)
+    P = (np.abs(Z * win.sum()) ** 2).T
+    assert p.shape == P.shape == (1 + y.size // 1024, 1025)
+    np.testing.assert_allclose(p, P, rtol=1e-4, atol=1e-3)
+    assert float(logmel_ref._hz_to_mel(1000.0)) == pytest.approx(15.0)
+    assert float(logmel_ref._hz_to_mel(500.0)) == pytest.approx(7.5)
+    assert float(logmel_ref._mel_to_hz(15.0 + 27.0)) == pytest.approx(6400.0)
+    np.testing.assert_allclose(logmel_ref._mel_to_hz(logmel_ref._hz_to_mel([40.0, 999.0, 1001.0, 8000.0, 22050.0])),
+                               [40.0, 999.0, 1001.0, 8000.0, 22050.0], rtol=1e-12)
+
+
 def test_model_deepcopy_and_pickle_rebuild_the_arena():
     import copy
     import io
