@@ -6,7 +6,7 @@
 // Two code paths (gfx950 only):
 //   * small  : Cin*Cout small (first layer, Cin in {1,2,4}; the 16-channel Lightning net).
 //              Direct VALU convolution, HBM-bound: coalesced 16 B/lane channel-last stores,
-//              mel-band halo tile + weights staged in LDS.
+//              mel-band halo tile in LDS; weights in registers (Cin <= 4) or LDS.
 //   * mfma   : Cin%32==0, Cout%32==0 (the 128-channel layers, K = 9*Cin = 1152): implicit GEMM
 //              on v_mfma_f32_32x32x2_f32 (exact fp32), (TT+2)x(FT+2) halo tile of 32 input
 //              channels in LDS read with conflict-free ds_read_b128 (TT time rows x FT mel columns per
