@@ -46,6 +46,33 @@ __device__ __forceinline__ f32x4 c1_conv(const C1W<CIN>& W, const float* __restr
     return acc;
 }
 
+// (1,2) pool: the conv outputs at time rows tl and tl+1 of one mel column from ONE 4x3xCIN halo patch (12 LDS reads
+// instead of 18); same FMA order as c1_conv, so the values are bit-identical to the other passes.
+template <int CIN>
+__device__ __forceinline__ void c1_conv2(const C1W<CIN>& W, const float* __restrict__ halo, int tl, int f, int F2,
+                                         f32x4& v0, f32x4& v1) {
+    float hv[4][3][CIN];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* hp = halo + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) hv[kw][kh][ci] = hp[ci];
+        }
+    v0 = W.b;
+    v1 = W.b;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                v0 += hv[kw][kh][ci] * W.w[(kh * 3 + kw) * CIN + ci];
+                v1 += hv[kw + 1][kh][ci] * W.w[(kh * 3 + kw) * CIN + ci];
+            }
+}
+
 template <int CIN>
 __device__ __forceinline__ void c1_stage(float* halo, const float* __restrict__ x, int b, int t0, int F, int T) {
     const int F2 = F + 2;
@@ -60,7 +87,8 @@ __device__ __forceinline__ void c1_stage(float* halo, const float* __restrict__ 
 }
 
 // MODE 0: stats  1: forward  2: backward reduce  3: backward apply + weight gradient
-template <int CIN, int MODE>
+// P12: the pool is (1,2): unrolled window, both conv outputs of a window from one halo patch, kept for the apply loop
+template <int CIN, int MODE, bool P12>
 __global__ __launch_bounds__(256) void conv1_fused_k(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
@@ -69,6 +97,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
     int B, int F, int T, int C, int pf, int pt, float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev) {
     if (seed_dev) seed += seed_dev[0] * 0x9E3779B97F4A7C15ull;   // per-step salt kept on the device (graph replay)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (P12) { pf = 1; pt = 2; }
     const int F2 = F + 2;
     float* halo = smem;                                       // [(TT+2)][F2][CIN]
     const int tid = threadIdx.x;
@@ -117,11 +146,15 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                 int tp = t0 / pt + tpl;
                 if (tp >= Tp) break;
                 size_t oi = ((((size_t)b * Tp + tp) * Fp + fp) * C4 + cg) * 4;   // channels-last index of the pooled element
+                f32x4 vw[2];
+                if (P12 && MODE >= 1) c1_conv2<CIN>(W, halo, tpl * 2, fp, F2, vw[0], vw[1]);
                 if (MODE == 1) {
                     f32x4 m = {0, 0, 0, 0};
-                    for (int df = 0; df < pf; ++df)
-                        for (int dt = 0; dt < pt; ++dt) {
-                            f32x4 z = c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2) * sc + sh;
+#pragma unroll
+                    for (int df = 0; df < (P12 ? 1 : pf); ++df)
+#pragma unroll
+                        for (int dt = 0; dt < (P12 ? 2 : pt); ++dt) {
+                            f32x4 z = (P12 ? vw[dt] : c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2)) * sc + sh;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], z[k]);
                         }
@@ -139,9 +172,11 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, bx = {0, 0, 0, 0};
                     int bidx[4] = {0, 0, 0, 0};
                     int widx = 0;
-                    for (int df = 0; df < pf; ++df)
-                        for (int dt = 0; dt < pt; ++dt, ++widx) {
-                            f32x4 v = c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2);
+#pragma unroll
+                    for (int df = 0; df < (P12 ? 1 : pf); ++df)
+#pragma unroll
+                        for (int dt = 0; dt < (P12 ? 2 : pt); ++dt, ++widx) {
+                            f32x4 v = P12 ? vw[dt] : c1_conv<CIN>(W, halo, tpl * pt + dt, fp * pf + df, F2);
                             f32x4 z = v * sc + sh;
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
@@ -155,10 +190,12 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                         a2 += g * bx;
                     } else {
                         widx = 0;
-                        for (int df = 0; df < pf; ++df)
-                            for (int dt = 0; dt < pt; ++dt, ++widx) {
+#pragma unroll
+                        for (int df = 0; df < (P12 ? 1 : pf); ++df)
+#pragma unroll
+                            for (int dt = 0; dt < (P12 ? 2 : pt); ++dt, ++widx) {
                                 const int tl = tpl * pt + dt, f = fp * pf + df;
-                                f32x4 v = c1_conv<CIN>(W, halo, tl, f, F2);
+                                f32x4 v = P12 ? vw[dt] : c1_conv<CIN>(W, halo, tl, f, F2);
                                 f32x4 o;
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
@@ -263,13 +300,17 @@ static int c1_launch(const float* x, const float* wp, const float* bias, const f
                      uint64_t seed, const uint64_t* seed_dev, hipStream_t s) {
     size_t lds = c1_lds(Cin, F, C, MODE);
     int grid = sed_conv1_fused_rows(B, T);
-    if (Cin == 1) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_fused_k<1, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_fused_k<2, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_fused_k<2, MODE><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);
-    }
+    const bool p12 = (pf == 1 && pt == 2);
+#define C1_LAUNCH(CIN_, P12_)                                                                                          \
+    do {                                                                                                               \
+        if (lds > 48 * 1024)                                                                                           \
+            (void)hipFuncSetAttribute((const void*)conv1_fused_k<CIN_, MODE, P12_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        conv1_fused_k<CIN_, MODE, P12_><<<grid, 256, lds, s>>>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, out, \
+                                                              partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);  \
+    } while (0)
+    if (Cin == 1) { if (p12) C1_LAUNCH(1, true); else C1_LAUNCH(1, false); }
+    else { if (p12) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
+#undef C1_LAUNCH
     return 0;
 }
 
