@@ -18,7 +18,7 @@
 #define CV_CIC 32   // input channels per LDS chunk
 #define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
 #define CV_MTW 5    // max 32-row tiles per wave
-#define WG_FT 40     // wgrad: max mel columns per tile (2 time rows)
+#define WG_FT 40     // wgrad: max mel columns per tile (2 time rows at that width; TT*FT <= 2*WG_FT)
 #define WG_NX 6      // wgrad: DMA items (float4) per thread of the halo tile   (4*(WG_FT+2)*8 <= 256*WG_NX)
 #define WG_ND 10     // wgrad: DMA items (float4) per thread of the dY tile     (2*WG_FT*32    <= 256*WG_ND)
 
@@ -48,8 +48,12 @@ static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nf
         if (FT == last_ft) continue;
         last_ft = FT;
         const int nf = cdiv(F, FT);
-        for (int TT = 1; TT <= 8 && TT <= T; ++TT) {
+        // tall tiles (TT > 8) only for a full-width narrow mel axis (the mel-pooled topologies: F = 8, 4 after pooling),
+        // and only while two blocks still fit the LDS of a CU
+        const int tt_max = (nft == 1) ? 64 : 8;
+        for (int TT = 1; TT <= tt_max && TT <= T; ++TT) {
             if (TT * FT > limit || (TT + 2) * (FT + 2) * 8 > 256 * CV_NH) continue;
+            if (TT > 8 && (size_t)2 * (TT + 2) * ((FT + 2) * CV_LD + CV_TPAD) * sizeof(float) > 80 * 1024) continue;
             double util = ((double)(TT * FT) / limit) * ((double)F / ((double)nf * FT)) * ((double)T / ((double)cdiv(T, TT) * TT));
             double score = util / (1.0 + 0.25 * ((double)(TT + 2) * (FT + 2) / (TT * FT) - 1.0));
             if (score > best) { best = score; *TT_out = TT; *FT_out = FT; *nft_out = nf; }
@@ -494,12 +498,16 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
     p.FT = F; p.nft = 1;
     if (p.kind == 1) {
-        // 2 time rows x (even) FT <= WG_FT mel columns, two LDS buffers (the DMA item budget of the kernel: WG_NX / WG_ND)
-        p.TT = 2;
+        // TT time rows x (even) FT <= WG_FT mel columns with TT*FT <= 2*WG_FT positions, two LDS buffers (the DMA item
+        // budget of the kernel: WG_NX / WG_ND); more rows for a narrow mel axis (the mel-pooled topologies)
         p.nft = cdiv(F, WG_FT);
         p.FT = cdiv(F, p.nft);
         p.FT += p.FT & 1;
-        p.lds = (size_t)2 * ((size_t)4 * (p.FT + 2) * 32 + (size_t)2 * p.FT * 128) * sizeof(float);
+        p.TT = 2;
+        while (p.TT + 2 <= 62 && p.TT + 2 <= T + (T & 1) && (p.TT + 2) * p.FT <= 2 * WG_FT &&
+               (p.TT + 4) * (p.FT + 2) * 8 <= 256 * WG_NX)
+            p.TT += 2;
+        p.lds = (size_t)2 * ((size_t)(p.TT + 2) * (p.FT + 2) * 32 + (size_t)p.TT * p.FT * 128) * sizeof(float);
     } else {
         p.TT = 4;
         if (p.TT > T) p.TT = T;
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* _
 // D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions; all nine
 // taps share one dY read (9 accumulator tiles per wave); operands of k-step s+1 are read from LDS while the 9 MFMAs of
 // step s issue (explicit two-stage register pipeline, one wave per SIMD).
-// A block walks tiles of TT = 2 time rows x FT mel columns through two LDS buffers; the next tile is brought in by
+// A block walks tiles of TT time rows x FT mel columns (TT*FT <= 80 positions: 2 x 40 at F = 40) through two LDS buffers; the next tile is brought in by
 // global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no commit pass, one barrier per tile) while the MFMA loop runs on
 // the current one.  The register-staged predecessor (4-row tiles, whole next tile prefetched into 112 VGPRs) ran at the
 // same 117 TFLOP/s but held 428 VGPRs and 114 KB of LDS per CU, which kept every other kernel off the CU; this one
@@ -680,9 +688,9 @@ typedef __attribute__((address_space(3))) void* sed_lptr_t;
 template <bool MT>
 __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
-    int B, int Cin, int F, int T, int Cout, int FT, int nft, int tblocks, int ntiles) {
+    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TT = 2, NX = WG_NX, ND = WG_ND;
+    constexpr int NX = WG_NX, ND = WG_ND;
     const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
     const int MROWS = TT * FT;
@@ -699,20 +707,20 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
     // per-thread, tile-invariant: element offset from the tile origin (b, t0, f0) and the halo / tile coordinates
-    //   xt = tt | ff << 3 (halo coordinates; ff huge: item past the tile), dt = tl | fl << 2 (fl huge: none)
+    //   xt = tt | ff << 6 (halo coordinates; ff huge: item past the tile), dt = tl | fl << 6 (fl huge: none)
     int xo[NX], xt[NX], dofs[ND], dt[ND];
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
         int i = tid + u * 256, row = i >> 3, q = i & 7;
         int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-        xt[u] = (i < HR * 8) ? (tt | (ff << 3)) : (1 << 24);
+        xt[u] = (i < HR * 8) ? (tt | (ff << 6)) : (1 << 24);
         xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
     }
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
         int i = tid + u * 256, row = i >> 5, q = i & 31;
         int tl = sed_fdiv(row, invF), fl = row - tl * FT;
-        dt[u] = (i < MROWS * 32) ? (tl | (fl << 2)) : (1 << 24);
+        dt[u] = (i < MROWS * 32) ? (tl | (fl << 6)) : (1 << 24);
         dofs[u] = (tl * F + fl) * Cout + co0 + q * 4;
     }
     auto issue = [&](int tile, float* buf) {          // global -> LDS (DMA); padding / out-of-range items are zeroed
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
         for (int u = 0; u < NX; ++u) {
             const int i = tid + u * 256;
             if (i < HR * 8) {
-                int t = t0 + (xt[u] & 7) - 1, f = f0 + (xt[u] >> 3) - 1;
+                int t = t0 + (xt[u] & 63) - 1, f = f0 + (xt[u] >> 6) - 1;
                 if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F)
                     __builtin_amdgcn_global_load_lds((sed_gptr_t)(xb + xo[u]), (sed_lptr_t)(buf + (u * 256 + wave * 64) * 4), 16, 0, 0);
                 else
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
         for (int u = 0; u < ND; ++u) {
             const int i = tid + u * 256;
             if (i < MROWS * 32) {
-                if (t0 + (dt[u] & 3) < T && f0 + (dt[u] >> 2) < F)
+                if (t0 + (dt[u] & 63) < T && f0 + (dt[u] >> 6) < F)
                     __builtin_amdgcn_global_load_lds((sed_gptr_t)(db + dofs[u]), (sed_lptr_t)(buf + XH + (u * 256 + wave * 64) * 4), 16, 0, 0);
                 else
                     *(f32x4*)(buf + XH + i * 4) = (f32x4){0, 0, 0, 0};
@@ -823,10 +831,10 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
         if (p.nft == 1) {
             SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
-            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.FT, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
         } else {
             SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
-            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.FT, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
         }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);

@@ -33,6 +33,8 @@ CONV_CASES = [  # B, Cin, F, T, Cout, nchw
     # mel axis wider than one block tile / not a multiple of the tile / odd; time extents that leave ragged last tiles
     (1, 128, 128, 11, 128, False), (1, 128, 50, 5, 128, False), (1, 128, 41, 6, 128, False), (1, 128, 200, 2, 128, False),
     (1, 32, 90, 9, 32, False), (1, 64, 130, 3, 64, False), (2, 128, 7, 5, 128, False), (1, 128, 40, 1, 128, False),
+    # narrow mel axis of the mel-pooled topologies: tall tiles (up to 35 time rows forward, 20 in the weight gradient)
+    (2, 128, 8, 44, 128, False), (1, 128, 4, 75, 128, False), (2, 128, 2, 9, 128, False), (1, 128, 8, 3, 128, False),
 ]
 
 

@@ -13,7 +13,9 @@ import sed_crnn_amd as sed
 from sed_crnn_amd import _lib
 from sed_crnn_amd.trainer import FusedTrainStep
 
+# "A" = the README-figure topology: mel pooling 5/2/2, no time pooling -> 256 serial GRU steps, 6 classes
 CONFIGS = {
+    "A": dict(B=128, Cin=1, F=40, T=256, C=128, H=32, figure=True),
     2: dict(B=128, Cin=1, F=40, T=256, C=128, H=128),
     3: dict(B=128, Cin=2, F=40, T=256, C=128, H=128),
     5: dict(B=128, Cin=4, F=128, T=512, C=128, H=256),
@@ -22,6 +24,10 @@ CONFIGS = {
 
 def flops_per_frame_train(c):
     T, F, C, H, Cin = c["T"], c["F"], c["C"], c["H"], c["Cin"]
+    if c.get("figure"):
+        conv = 2 * 9 * C * T * (Cin * 40 + C * 8 + C * 4)
+        gru = 2 * 2 * T * 3 * H * (C * 2 + H) + 2 * 2 * T * 3 * H * (2 * H + H)
+        return 3.0 * (conv + gru) / T
     conv = 2 * 9 * C * F * (Cin * T + C * T // 2 + C * T // 4)
     Tp = T // 8
     gru = 2 * 2 * Tp * 3 * H * (C * F + H) + 2 * 2 * Tp * 3 * H * (2 * H + H)
@@ -31,10 +37,15 @@ def flops_per_frame_train(c):
 def run(k, steps, breakdown=False):
     c = CONFIGS[k]
     torch.manual_seed(0)
-    m = sed.TimePooledCRNN(conv_channels=c["C"], dropout=0.5, in_channels=c["Cin"], n_mels=c["F"], gru_hidden=c["H"]).cuda()
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(c["B"], c["Cin"], c["F"], c["T"], generator=g).cuda()
-    y = (torch.rand(c["B"], c["T"] // 8, 1, generator=g) > 0.8).float().cuda()
+    if c.get("figure"):
+        m = sed.get_model(in_channels=1, n_mels=40, seq_len=c["T"], n_classes=6, conv_channels=c["C"],
+                          pools=[(5, 1), (2, 1), (2, 1)], rnn_hidden=[c["H"], c["H"]], fc=[16, 6]).cuda()
+        y = (torch.rand(c["B"], c["T"], 6, generator=g) > 0.8).float().cuda()
+    else:
+        m = sed.TimePooledCRNN(conv_channels=c["C"], dropout=0.5, in_channels=c["Cin"], n_mels=c["F"], gru_hidden=c["H"]).cuda()
+        y = (torch.rand(c["B"], c["T"] // 8, 1, generator=g) > 0.8).float().cuda()
     st = FusedTrainStep(m, lr=1e-3, loss="bce")
     for _ in range(3):
         loss, _ = st.step(x, y)
@@ -85,7 +96,7 @@ if __name__ == "__main__":
     ap.add_argument("--configs", default="2,3,5")
     ap.add_argument("--breakdown", action="store_true")
     a = ap.parse_args()
-    for k in [int(s) for s in a.configs.split(",")]:
+    for k in [s if s == "A" else int(s) for s in a.configs.split(",")]:
         run(k, a.steps, a.breakdown)
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
