@@ -560,3 +560,20 @@ def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
     assert d.mean() < 1e-2 and d.max() < 0.1, (d.mean(), d.max())
     sure = np.abs(pr - 0.5) > 0.1
     assert np.array_equal((ph > 0.5)[sure], (pr > 0.5)[sure])
+
+
+def test_long_recording_single_sequence_inference_matches_oracle(sed):
+    """streaming-style inference: one 2048-frame sequence (B = 1, 256 GRU steps) through the full-width net in eval mode"""
+    from oracle import crnn_ref
+    torch.manual_seed(17)
+    kw = dict(conv_channels=128, dropout=0.5, gru_hidden=32)
+    ref = crnn_ref.SedNetRef(**kw).eval()
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().eval()
+    x = torch.randn(1, 1, 40, 2048, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        pr = torch.sigmoid(ref(x))
+        ph = torch.sigmoid(m(x.cuda())).cpu()
+    assert ph.shape == (1, 256, 1)
+    _cmp(ph, pr, atol=1e-4)
