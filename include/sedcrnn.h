@@ -150,12 +150,13 @@ int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias
  * two strides must be 1.  Exact fp32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain). */
 int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
                  float* C, long ldc, const float* bias, float beta, int M, int N, int K, void* stream);
-/* Same product (no bias, beta = 0) with an optional scratch buffer: small-output / long-K shapes (the GRU
- * weight gradients, M*N small, K = B*T') are split along K into fixed slices and summed in slice order
- * (deterministic).  workspace >= sed_gemm_f32_workspace_bytes(M,N,K) (0 = the shape is not split). */
+/* Same product (optional bias, beta = 0) with a scratch buffer: small-output / long-K shapes (the GRU weight
+ * gradients, M*N small, K = B*T'; the input projection of a small batch, M = B*T' small, K = C*F') would leave most
+ * CUs without a tile, so they are split along K into fixed slices that are summed in slice order (deterministic; the
+ * bias is added by the summing pass).  workspace >= sed_gemm_f32_workspace_bytes(M,N,K) (0 = the shape is not split). */
 size_t sed_gemm_f32_workspace_bytes(int M, int N, int K);
 int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
-                    float* C, long ldc, int M, int N, int K, void* workspace, void* stream);
+                    float* C, long ldc, const float* bias, int M, int N, int K, void* workspace, void* stream);
 
 /* Small dense layer y = act(x W^T + b) for the time-distributed head (sed.py:103,112;
  * crnn_lightning.py:63-64,72-73). x [M][K], W [N][K], y [M][N]; relu=1 applies ReLU. */

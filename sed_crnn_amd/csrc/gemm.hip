@@ -247,13 +247,15 @@ static int launch_gemm(bool akc, bool bkc, hipStream_t s, const float* A, long a
 }
 
 // C[i][j] = sum_z slab[z][i][j] in slab order
-__global__ void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits, int M, int N, float* __restrict__ C, long ldc) {
+__global__ void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits, int M, int N, float* __restrict__ C, long ldc,
+                                     const float* __restrict__ bias) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long n = (long)M * N;
     if (i >= n) return;
     float a = 0.f;
 #pragma unroll 8
     for (int z = 0; z < splits; ++z) a += slabs[(size_t)z * n + i];
+    if (bias) a += bias[i % N];
     C[(i / N) * ldc + (i % N)] = a;
 }
 
@@ -288,13 +290,13 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
     SedProfScope prof(SED_K_GEMM, s, 2.0 * M * (double)N * K);
     const int splits = workspace ? gemm_splits(M, N, K) : 1;
     if (splits > 1) {
-        SED_REQUIRE(!bias && beta == 0.f, "gemm_f32: split-K path takes no bias / beta");
+        SED_REQUIRE(beta == 0.f, "gemm_f32: split-K path takes no beta");
         int k_len = ((cdiv(K, splits) + GM_BK - 1) / GM_BK) * GM_BK;
         int rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, (float*)workspace, N, nullptr, 0.f, M, N, K, av, bv,
                                    cdiv(K, k_len), k_len, (long)M * N);
         if (rc) return rc;
         SED_LAUNCH_CHECK("gemm_f32 (split-K)");
-        gemm_splitk_reduce_k<<<cdiv((long)M * N, 256), 256, 0, s>>>((const float*)workspace, cdiv(K, k_len), M, N, C, ldc);
+        gemm_splitk_reduce_k<<<cdiv((long)M * N, 256), 256, 0, s>>>((const float*)workspace, cdiv(K, k_len), M, N, C, ldc, bias);
         SED_LAUNCH_CHECK("gemm_splitk_reduce");
         return 0;
     }
@@ -333,8 +335,8 @@ extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B
 }
 
 extern "C" int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
-                               long ldc, int M, int N, int K, void* workspace, void* stream) {
-    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, nullptr, 0.f, M, N, K, workspace, stream);
+                               long ldc, const float* bias, int M, int N, int K, void* workspace, void* stream) {
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, 0.f, M, N, K, workspace, stream);
 }
 
 // ───────────────────────── small dense head ─────────────────────────

@@ -124,12 +124,18 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         for (int i = 0; i < c->n_gru; ++i) L->dgout[i] = cv.take(M * 2 * c->H[i]);
         for (int j = 0; j < c->n_dense - 1; ++j) L->dact[j] = cv.take(M * c->D[j]);
         L->lin_ws = cv.take(max_lin_ws);
+    }
+    {   // split-K scratch of the GEMMs: forward input projections (small batches), and in training the weight gradients
         size_t gw = 0;
         for (int i = 0; i < c->n_gru; ++i) {
-            size_t a = sed_gemm_f32_workspace_bytes(3 * c->H[i], c->H[i], L->M) / sizeof(float);
-            size_t b = sed_gemm_f32_workspace_bytes(6 * c->H[i], L->gr[i].in, L->M) / sizeof(float);
-            if (a > gw) gw = a;
-            if (b > gw) gw = b;
+            size_t f = sed_gemm_f32_workspace_bytes(L->M, 6 * c->H[i], L->gr[i].in) / sizeof(float);
+            if (f > gw) gw = f;
+            if (training) {
+                size_t a = sed_gemm_f32_workspace_bytes(3 * c->H[i], c->H[i], L->M) / sizeof(float);
+                size_t b = sed_gemm_f32_workspace_bytes(6 * c->H[i], L->gr[i].in, L->M) / sizeof(float);
+                if (a > gw) gw = a;
+                if (b > gw) gw = b;
+            }
         }
         L->gemm_ws = cv.take(gw + 64);
     }
@@ -217,7 +223,7 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         // both directions in ONE GEMM (N = 6H) when their weights/biases are adjacent (the flat arena lays them so)
         const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K && p->gru_bih[i][1] == p->gru_bih[i][0] + 3 * H;
         if (fused) {
-            SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][0], 1, K, ws + L.gi[i], 6 * H, p->gru_bih[i][0], 0.f, M, 6 * H, K, stream));
+            SED_TRY(sed_gemm_f32_ws(gin, K, 1, p->gru_wih[i][0], 1, K, ws + L.gi[i], 6 * H, p->gru_bih[i][0], M, 6 * H, K, ws + L.gemm_ws, stream));
         } else {
             for (int d = 0; d < 2; ++d)
                 SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
@@ -365,7 +371,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, dbih, dbhh, ws + L.gru_bws, B, L.Tp, H, stream));
             for (int d = 0; d < 2; ++d)      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
                 SED_TRY(sed_gemm_f32_ws(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
-                                        g->gru_whh[i][d], H, 3 * H, H, M, ws + L.gemm_ws, stream));
+                                        g->gru_whh[i][d], H, nullptr, 3 * H, H, M, ws + L.gemm_ws, stream));
             const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
                                g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
             // data gradient first: for layer 0 it is the input of the top conv block's BatchNorm backward, which then runs
@@ -385,7 +391,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 (void)hipEventRecord(ev_bn[top], s_aux);
             }
             if (fused) {
-                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
+                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, nullptr, 6 * H, K, M, ws + L.gemm_ws, stream));
             } else {
                 for (int d = 0; d < 2; ++d)
                     SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));

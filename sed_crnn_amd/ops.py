@@ -114,8 +114,8 @@ def gemm(A, B, bias=None, out=None, beta=0.0):
     return out
 
 
-def gemm_ws(A, B, out=None):
-    """out = A @ B through the split-K capable entry (workspace allocated here)."""
+def gemm_ws(A, B, out=None, bias=None):
+    """out = A @ B (+bias) through the split-K capable entry (workspace allocated here)."""
     M, K = A.shape
     _, N = B.shape
     if out is None:
@@ -123,7 +123,7 @@ def gemm_ws(A, B, out=None):
     nb = lib().sed_gemm_f32_workspace_bytes(M, N, K)
     ws = torch.empty(nb // 4 + 1, device=A.device) if nb else None
     check(lib().sed_gemm_f32_ws(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
-                                out.stride(0), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_ws")
+                                out.stride(0), ptr(bias), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_ws")
     return out
 
 

@@ -359,10 +359,13 @@ def test_cfg2_eval_matches_oracle_on_a_slice_and_is_batch_separable(sed, cfg2_mo
     m.eval()
     with torch.no_grad():
         full = m(x.cuda())
-        # eval mode has no cross-sample coupling: any sub-batch reproduces its rows exactly
+        # eval mode has no cross-sample coupling: any sub-batch reproduces its rows (to rounding: a 4-sample batch takes
+        # the split-K input projection, which sums K in a different order than the full batch's single pass)
         part = m(x[40:44].cuda())
+        part32 = m(x[32:64].cuda())                 # same GEMM path as the full batch: bit-identical
     assert full.shape == (128, 32, 1)
-    assert torch.equal(full[40:44], part)
+    assert torch.equal(full[32:64], part32)
+    _cmp(full[40:44], part, atol=2e-6)
     ref = crnn_ref.SedNetRef(conv_channels=128, dropout=0.5, gru_hidden=128)
     ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     ref.eval()
