@@ -2,17 +2,30 @@
 """bench.py — mel-frames/s of the SEDnet fit step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step is one full fit step of the hot path on one resident synthetic batch: forward (train-mode
 BatchNorm, dropout 0.5) + BCEWithLogits + backward + (gradient all-reduce over RCCL) + Adam, i.e.
 reference sed.py:134-137.  Workload = BASELINE config 2 per GPU (mono, B=128, 256 frames x 40 mel,
 3x conv128 + BiGRU 2x128), weak scaling: every rank trains its own 128-sample shard of the global
 batch, gradients averaged.  Prints ONE JSON line on rank 0.
+
+Launching.  One process per GPU.  Three ways in, one code path (`run_rank`):
+  * `python bench.py --gpus 1`              -> this process is rank 0 of 1;
+  * under torchrun (RANK/WORLD_SIZE set)     -> this process is the rank torchrun says;
+  * `python bench.py --gpus N`, N > 1, no torchrun environment -> this process is only a LAUNCHER: before any GPU
+    call it starts N fresh children of this same script with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, forwards rank 0's
+    JSON line and exits with the worst child code.  It never touches the GPU itself and never re-execs.
+`n_gpus` in the JSON line is the world size the process group itself reports (all-reduce of ones), not the flag.
+
+`--plumbing-only` (used by the CPU tests, gloo): launch, rendezvous, parameter broadcast, the staged all-reduce of the
+flat gradient arena and the max-over-ranks clock — everything of the N-rank path except the HIP kernels.  Its JSON line
+says `"metric": "plumbing-only"` and carries no throughput, so it can never be read as a bench result.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(B=128, Cin=1, F=40, T=256, C=128, H=128, gru_layers=2, dropout=0.5)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-
+PROFILE_ROUNDS = ("r2", "r1")         # newest committed PMC summary first
 
 DOMINANT_KERNEL = "conv3x3_mfma_fwd2_k<4, 2>"
 
@@ -29,90 +42,209 @@ DOMINANT_KERNEL = "conv3x3_mfma_fwd2_k<4, 2>"
 def pmc_traffic_bytes():
     """HBM traffic per launch of the dominant kernel, from the committed PMC summary (collected as the
     MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes; FETCH_SIZE counts half of a wide
-    coalesced read on gfx950, verified here on the pure-streaming bn kernel).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_fetch_write_per_kernel.json")
+    coalesced read on gfx950, verified here on the pure-streaming bn kernel).  (None, None) when no summary is committed."""
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_fetch_write_per_kernel.json")
+        try:
+            d = json.load(open(path))
+            e = d["void " + DOMINANT_KERNEL]
+            return int((2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024), rnd
+        except Exception:
+            continue
+    return None, None
+
+
+# ───────────────────────── CPU baseline (BASELINE.md §2 / SURVEY §8d) ─────────────────────────
+def host_cpu_info():
+    """What this process may actually use: scheduler affinity, cgroup CPU quota, physical cores among the allowed CPUs."""
+    logical = os.cpu_count() or 1
     try:
-        d = json.load(open(path))
-        e = d["void " + DOMINANT_KERNEL]
-        return int((2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024)
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(logical))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
     except Exception:
-        return None
+        pass
+    model, cores = "unknown", set()
+    try:
+        cur = {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (s.strip() for s in line.split(":", 1))
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    model = cur.get("model name", model)
+                cur = {}
+    except Exception:
+        pass
+    physical = len(cores) or len(allowed)
+    threads = max(1, min(len(allowed), physical, int(quota) if quota and quota >= 1 else len(allowed)))
+    return dict(cpu_model=model, logical_cpus=logical, allowed_cpus=len(allowed), cgroup_quota_cpus=quota,
+                physical_cores_allowed=physical, threads=threads)
 
 
-def cpu_baseline(sample_B=8, steps=3):
-    """The oracle's fit step (torch.nn CPU restatement of sed.py, pinned by tests/golden) on the host cores."""
+def cpu_baseline(steps=5):
+    """The oracle's fit step (torch.nn CPU restatement of sed.py, pinned by tests/golden) on the host cores: zero_grad +
+    forward + BCEWithLogits + backward + Adam(1e-3), dropout active, BN in train mode; median of `steps` after 1 warm-up.
+    Headline = c1 (the reference's own net, C=128 / GRU 2x32, B=16 x 256 frames: BASELINE.md §2); also the bench
+    workload's net (c2: GRU 2x128) at the same B=16, so the GPU line has a like-for-like row."""
     import torch
     from oracle import crnn_ref
-    w = WORKLOAD
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = crnn_ref.SedNetRef(conv_channels=w["C"], dropout=w["dropout"], in_channels=w["Cin"], n_mels=w["F"],
-                             gru_hidden=w["H"], gru_layers=w["gru_layers"])
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
-    x, y = crnn_ref.synthetic_batch(sample_B, w["Cin"], w["F"], w["T"], w["T"] // 8, seed=1234)
-    crnn_ref.fit_step(net, opt, x, y)                       # warm-up
-    ts = []
-    for _ in range(steps):
-        t0 = time.perf_counter()
-        crnn_ref.fit_step(net, opt, x, y)
-        ts.append(time.perf_counter() - t0)
-    ts.sort()
-    med = ts[len(ts) // 2]
-    return {"value": round(sample_B * w["T"] / med, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} fit steps (median) of the same net at B={sample_B}, T={w['T']} (torch {torch.__version__} CPU, "
-                      f"{cores} threads); {med*1e3:.0f} ms/step"}
+    info = host_cpu_info()
+    torch.set_num_threads(info["threads"])
+
+    def timed(H, B):
+        torch.manual_seed(0)
+        w = WORKLOAD
+        net = crnn_ref.SedNetRef(conv_channels=w["C"], dropout=w["dropout"], in_channels=w["Cin"], n_mels=w["F"],
+                                 gru_hidden=H, gru_layers=w["gru_layers"])
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        x, y = crnn_ref.synthetic_batch(B, w["Cin"], w["F"], w["T"], w["T"] // 8, seed=1234)
+        crnn_ref.fit_step(net, opt, x, y)                       # warm-up
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            crnn_ref.fit_step(net, opt, x, y)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        return B * w["T"] / med, med
+
+    c1, c1_med = timed(32, 16)
+    c2, c2_med = timed(WORKLOAD["H"], 16)
+    return {"value": round(c1, 1), "unit": "mel-frames/s", "cores": info["threads"], "kind": "port",
+            "sample": f"c1 = reference net (C128, GRU 2x32) at B=16 x 256 frames: median of {steps} fit steps after 1 warm-up, "
+                      f"{c1_med*1e3:.0f} ms/step, torch {torch.__version__} CPU with {info['threads']} threads",
+            "c2_net": {"value": round(c2, 1), "unit": "mel-frames/s",
+                       "sample": f"the bench workload's net (C128, GRU 2x128) at B=16 x 256 frames, same protocol, {c2_med*1e3:.0f} ms/step"},
+            "host": info}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--breakdown", action="store_true", help="per-kernel-family times of 2 extra steps on stderr")
-    args = ap.parse_args()
+# ───────────────────────── launcher (N > 1 without torchrun) ─────────────────────────
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes of this script.  The launcher has not imported torch and makes no GPU call."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] rank processes failed: {bad}", file=sys.stderr)
+        return max(abs(c) for _, c in bad) or 1
+    return 0
+
+
+# ───────────────────────── one rank ─────────────────────────
+def run_rank(args):
     import torch
     import torch.distributed as dist
     import sed_crnn_amd as sed
-    from sed_crnn_amd import _lib
-    from sed_crnn_amd.dist import broadcast_parameters, init_from_env
-    from sed_crnn_amd.trainer import FusedTrainStep
+    from sed_crnn_amd.dist import BucketedAllReduce, broadcast_parameters, init_from_env
 
-    rank, world, local = init_from_env("nccl")
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    w = WORKLOAD
-    torch.manual_seed(0)
+    plumbing = args.plumbing_only
+    backend = args.backend or ("gloo" if plumbing else "nccl")
+    if not plumbing:
+        want = int(os.environ.get("WORLD_SIZE", "1"))
+        have = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+        if have < want:
+            raise SystemExit(f"[bench] {want} ranks requested but only {have} GPU(s) visible: refusing to share a GPU")
+    rank, world, local = init_from_env(backend)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the process group has {world} ranks")
+    on_gpu = not plumbing
+    if on_gpu:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    w = dict(WORKLOAD)
+    if plumbing:
+        w.update(C=8, H=8)                                    # a small arena: this mode measures nothing
+    torch.manual_seed(0 if not plumbing else rank)           # plumbing: prove the broadcast by starting different
     model = sed.TimePooledCRNN(conv_channels=w["C"], dropout=w["dropout"], in_channels=w["Cin"], n_mels=w["F"],
                                gru_hidden=w["H"], gru_layers=w["gru_layers"]).to(dev)
     if world > 1:
         broadcast_parameters(model)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                 # the world size as the collective library sees it
+        world_seen = int(ones.item())
+    else:
+        world_seen = 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local]) if on_gpu else dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    base = {"n_gpus": world_seen, "steps": args.steps, "warmup": args.warmup}
+    if plumbing:
+        red = BucketedAllReduce(model.flat_grads(), model.bucket_slices()) if world > 1 else None
+        g = model.flat_grads()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.fill_(float(rank + 1))
+            if red is not None:
+                for s in range(len(model.bucket_slices())):
+                    red.launch(s)
+                red.wait_all()
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        expect = sum(range(1, world + 1)) / world
+        ok = bool(torch.allclose(g, torch.full_like(g, expect)))
+        psum = torch.tensor([float(model.flat_parameters().double().sum())], dtype=torch.float64)
+        lo, hi = psum.clone(), psum.clone()
+        if world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps(dict(base, metric="plumbing-only", value=None, backend=backend, allreduce_avg_ok=ok,
+                                  params_in_sync=bool(lo.item() == hi.item()), ms_per_step=round(dt.item() / args.steps * 1e3, 4),
+                                  config={"parallelism": f"dp{world_seen}"})), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0 if ok else 1
+
+    import ctypes as C
+    from sed_crnn_amd import _lib
+    from sed_crnn_amd.trainer import FusedTrainStep
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(w["B"], w["Cin"], w["F"], w["T"], generator=g).to(dev)
     y = (torch.rand(w["B"], w["T"] // 8, 1, generator=g) > 0.8).float().to(dev)
     step = FusedTrainStep(model, lr=1e-3, loss="bce")
-
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step.step(x, y)
     lib = _lib.lib()
     tag = 0                                                  # SED_K_CONV_MFMA_FWD: the dominant kernel
     barrier()
-    lib.sed_prof_enable(1 << tag)                            # 8 event records per step; nothing else instrumented
+    lib.sed_prof_enable(1 << tag)                            # measurement-only: 8 event records per step on the launch stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step.step(x, y)
     barrier()
     dt = time.perf_counter() - t0
-    import ctypes as C
     ms, n, units = C.c_double(), C.c_long(), C.c_double()
     lib.sed_prof_read(tag, C.byref(ms), C.byref(n), C.byref(units))
     lib.sed_prof_enable(0)
@@ -128,7 +260,7 @@ def main():
             step.step(x, y)
         torch.cuda.synchronize()
         tot = 0.0
-        for k in range(11):
+        for k in range(lib.sed_prof_tag_count()):
             lib.sed_prof_read(k, C.byref(ms2 := C.c_double()), C.byref(n2 := C.c_long()), C.byref(u2 := C.c_double()))
             if n2.value:
                 rate = u2.value / (ms2.value * 1e-3) / 1e12
@@ -139,14 +271,12 @@ def main():
         lib.sed_prof_enable(0)
 
     if rank == 0:
-        frames = w["B"] * w["T"] * world * args.steps
-        out = {
+        frames = w["B"] * w["T"] * world_seen * args.steps
+        out = dict(base)
+        out.update({
             "metric": "mel-frames/sec training throughput (seq=256, mel=40)",
             "value": round(frames / dt, 1),
             "unit": "mel-frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -155,17 +285,20 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: mono (B={w['B']},256,40,1) per GPU, 3xConv3x3(128)+BN+ReLU+pool(1,2)+dropout0.5, "
                                    f"BiGRU 2x128, Linear(256,1), BCEWithLogits, Adam lr 1e-3; full fit step (fwd+loss+bwd+allreduce+Adam)",
-                       "global_batch": w["B"] * world, "seq_len": w["T"], "n_mels": w["F"],
-                       "parallelism": f"dp{world}" if world > 1 else "single", "final_loss": round(final_loss, 6)},
-        }
+                       "global_batch": w["B"] * world_seen, "seq_len": w["T"], "n_mels": w["F"],
+                       "parallelism": f"dp{world_seen}" if world_seen > 1 else "single", "final_loss": round(final_loss, 6)},
+        })
+        out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data", "config")}
         if n.value:
             avg_ms = ms.value / n.value
             tf = units.value / (ms.value * 1e-3) / 1e12
+            traffic, rnd = pmc_traffic_bytes()
             out["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (conv2/conv3 forward + their data gradients)",
                                "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
-                               "traffic_note": "HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this "
-                                               "command (profiles/r1): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
+                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_note": f"HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this "
+                                               f"command (profiles/{rnd}): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
                                "flops_per_launch_avg": units.value / n.value}
         if not args.no_cpu_baseline:
@@ -173,6 +306,25 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="per-kernel-family times of 2 extra steps on stderr")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="exercise launch + rendezvous + staged all-reduce without the HIP kernels (CPU tests); not a benchmark")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --plumbing-only)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("[bench] --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # launcher only: no torch import, no GPU call above this line
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

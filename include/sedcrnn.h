@@ -13,7 +13,9 @@
  *   - the CALLER owns every buffer (inputs, outputs, workspace); the library never
  *     allocates or frees device memory and keeps no pointer past return;
  *   - every launch is asynchronous on the hipStream_t passed as `stream`
- *     (void*; NULL = the default stream); no entry synchronises the device;
+ *     (void*; NULL = the default stream); no entry synchronises the device and the entries are
+ *     re-entrant (no mutable process state) — with ONE exception, the measurement-only
+ *     sed_prof_* group at the end of this header, which is off by default;
  *   - return value: 0 = ok, <0 = argument / shape error, >0 = hipError_t.  The message
  *     of the last failure on the calling thread is sed_last_error_string().
  *
@@ -230,16 +232,26 @@ int sed_window_batch(const float* mel, const float* lab, long N, int C, int F, i
 /* utils.split_in_seqs + split_multi_channels in one pass: feat [N][C*F] -> out [N/S][C][F][S] (time_last=1, network
  * input) or [N/S][C][S][F] (time_last=0, the utils.py layout); the N %% S remainder is dropped. */
 int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_last, float* out, void* stream);
-/* StandardScaler.fit (feature.py:127-128): per-column mean and population sigma (sigma 0 -> 1). */
+/* StandardScaler.fit (feature.py:127-128): per-column mean and population sigma with sklearn's rules — float64
+ * accumulation, centred two-pass variance, and scale 1 for a column whose variance is within that algorithm's rounding
+ * bound (sklearn's _is_constant_feature: var <= N*eps*var + (N*mean*eps)^2).  x [N][F] f32, F <= 256; mean / stdv are
+ * FLOAT64 device arrays [F], like sklearn's mean_ / scale_ (a float32 mean would already cost 5 % of a sigma on a column
+ * whose mean is 1e6 sigmas). */
 size_t sed_col_mean_std_workspace_bytes(int F);
-int sed_col_mean_std(const float* x, long N, int F, float* mean, float* stdv, void* workspace, void* stream);
+int sed_col_mean_std(const float* x, long N, int F, double* mean, double* stdv, void* workspace, void* stream);
+/* StandardScaler.transform (feature.py:128-129): out = f32(f32(x - mean[col]) / stdv[col]) (sklearn's two in-place
+ * float32 roundings); mean / stdv float64 [F]; out may alias x. */
+int sed_col_standardize(const float* x, long N, int F, const double* mean, const double* stdv, float* out, void* stream);
 
-/* Segment-based metric counts (metrics.py:20-68) of thresholded predictions on the device: pred/lab [rows][K]
- * (windows concatenated, K <= 32), 1-second blocks of `block` rows.  counts13 (uint64, device):
+/* Segment-based metric counts (metrics.py:20-68) and the 2x2 confusion counts (crnn_lightning.py:112-119) of thresholded
+ * predictions on the device: pred/lab [rows][K] (windows concatenated, K <= 32; labels are 0/1), 1-second blocks of
+ * `block` rows.  counts17 (uint64, device):
  * [0..5] frame-wise TP,Nref,Nsys,S,D,I; [6..8] TP,Nref,Nsys over ceil(rows/block) blocks (F1 keeps the partial block);
- * [9..12] S,D,I,Nref over floor(rows/block) blocks (ER drops it).  Integer arithmetic: exact. */
+ * [9..12] S,D,I,Nref over floor(rows/block) blocks (ER drops it); [13..16] element-wise tn,fp,fn,tp with the
+ * reference's uint8 truncation of the label (label in [0,1) counts as 0, [1,2) as 1).  Integer arithmetic: exact. */
+#define SED_SEGMENT_COUNTS 17
 int sed_segment_counts(const float* pred, const float* lab, long rows, int K, int block, float threshold,
-                       unsigned long long* counts13, void* stream);
+                       unsigned long long* counts17, void* stream);
 
 /* ───────────── whole-network plan (TimePooledCRNN.forward sed.py:105-112 / crnn_lightning.py:66-73) ───────────── */
 typedef struct sed_net_cfg {
@@ -314,11 +326,15 @@ int sed_net_backward_phases(const sed_net_cfg* cfg, const sed_net_params* p, con
                             const float* x, const float* dlogits, void* workspace, uint64_t seed,
                             int phase_begin, int phase_end, float count_scale, void* stream);
 
-/* ───────────── in-library kernel timers (measurement only; off by default) ─────────────
+/* ───────────── in-library kernel timers — MEASUREMENT ONLY, off by default ─────────────
+ * The one exception to the conventions at the top of this header: this group keeps process-wide mutable state (the
+ * enabled mask and the recorded event pairs, guarded by a mutex) and sed_prof_read SYNCHRONISES (hipEventSynchronize
+ * on every recorded pair).  Nothing in the product path enables it; bench.py does, for the `roofline` object.
  * When a tag's bit is set in `tag_mask`, every launch of that kernel family is bracketed by a pair of
  * hipEvents on the launch stream and tagged with its algorithmic work (FLOPs for the MFMA kernels,
  * bytes for the streaming ones).  sed_prof_read waits for the recorded events and returns the totals
- * since the last sed_prof_enable.  Process-wide state, not thread-safe; costs nothing when disabled. */
+ * since the last sed_prof_enable.  With the mask at 0 (the default) every entry is exactly as documented above:
+ * no event is recorded and no state is touched. */
 enum sed_kernel_tag {
     SED_K_CONV_MFMA_FWD = 0,   /* units: FLOPs */
     SED_K_CONV_SMALL_FWD,      /* units: bytes */
@@ -336,6 +352,7 @@ enum sed_kernel_tag {
 int sed_prof_enable(unsigned tag_mask);
 int sed_prof_read(int tag, double* total_ms, long* launches, double* total_units);
 const char* sed_prof_tag_name(int tag);
+int sed_prof_tag_count(void);                /* = SED_K_COUNT of the loaded library */
 
 #ifdef __cplusplus
 }

@@ -77,8 +77,49 @@ def mbe(y, sr=44100, n_fft=2048, hop=1024, n_mels=40, pad_mode="constant"):
 
 
 def standardize_fit(x):
-    """sklearn StandardScaler semantics (feature.py:127-129): population sigma, ddof=0."""
-    mu = x.mean(axis=0)
-    sd = x.std(axis=0)
-    sd = np.where(sd == 0, 1.0, sd)
-    return mu, sd
+    """sklearn StandardScaler.fit as feature.py:127-128 uses it -> (mean_, scale_) float64.
+
+    Restates sklearn 1.7 (preprocessing/_data.py StandardScaler.partial_fit, utils/extmath.py _incremental_mean_and_var,
+    _is_constant_feature, _handle_zeros_in_scale): float64 accumulators, population variance (ddof 0) from the centred
+    second pass  (sum d^2 - (sum d)^2 / n) / n,  and scale 1 for a column whose variance is within the rounding bound of
+    that algorithm,  var <= n*eps*var + (n*mean*eps)^2.  Pinned by tests/golden/g9_scaler.npz (generated with the
+    installed scikit-learn by oracle/make_goldens.py)."""
+    x64 = np.asarray(x, dtype=np.float64)
+    n = x64.shape[0]
+    mean = x64.sum(axis=0) / n
+    d = x64 - mean
+    var = ((d * d).sum(axis=0) - d.sum(axis=0) ** 2 / n) / n
+    eps = np.finfo(np.float64).eps
+    constant = var <= n * eps * var + (n * mean * eps) ** 2
+    scale = np.sqrt(var)
+    scale[constant] = 1.0
+    return mean, scale
+
+
+def standardize_apply(x, mean, scale):
+    """StandardScaler.transform on a float32 matrix: sklearn subtracts and divides IN PLACE, so the float64 statistics
+    are applied with a rounding to float32 after each of the two steps."""
+    out = np.array(x, dtype=np.float32, copy=True)
+    out -= mean
+    out /= scale
+    return out
+
+
+def scaler_fixture_inputs(seed=77, n_train=1500, n_test=200, n_cols=40):
+    """Seeded (RandomState: a frozen stream) train / test matrices of the g9 golden, float32, with the columns that make
+    a scaler interesting: exactly constant (non-zero and zero), constant up to one float32 ulp, mean = 1e6 sigma, tiny
+    sigma, and ordinary log-mel-like columns."""
+    rs = np.random.RandomState(seed)
+    sig = rs.uniform(0.5, 3.0, n_cols)
+    mu = rs.uniform(-8.0, 4.0, n_cols)
+
+    def draw(n):
+        x = (rs.randn(n, n_cols) * sig + mu).astype(np.float32)
+        x[:, 3] = 3.25
+        x[:, 4] = 0.0
+        x[:, 5] = np.float32(0.1)
+        x[n // 2, 5] = np.nextafter(np.float32(0.1), np.float32(1.0))
+        x[:, 6] = (1.0e4 + 1.0e-2 * rs.randn(n)).astype(np.float32)
+        x[:, 7] = (1.0e-6 * rs.randn(n)).astype(np.float32)
+        return x
+    return draw(n_train), draw(n_test)

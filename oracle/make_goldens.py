@@ -57,7 +57,30 @@ def sd_np(model, prefix="sd."):
     return {prefix + k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
 
 
+def golden_scaler():
+    """G9: sklearn.preprocessing.StandardScaler exactly as feature.py:127-129 calls it (fit_transform on the train
+    split, transform on the test split), on the seeded matrices of oracle.logmel_ref.scaler_fixture_inputs.  Only the
+    seed and sklearn's outputs are stored; scikit-learn is importable in the build container (not on the GPU box)."""
+    import sklearn
+    from sklearn import preprocessing
+    from oracle.logmel_ref import scaler_fixture_inputs
+    seed = 77
+    xtr, xte = scaler_fixture_inputs(seed)
+    scaler = preprocessing.StandardScaler()
+    ttr = scaler.fit_transform(xtr.copy())
+    tte = scaler.transform(xte.copy())
+    d = {"seed": np.int64(seed), "mean_": scaler.mean_, "var_": scaler.var_, "scale_": scaler.scale_,
+         "n_samples_seen_": np.int64(scaler.n_samples_seen_), "train_t": ttr, "test_t": tte,
+         "sklearn_version": np.asarray(sklearn.__version__)}
+    assert ttr.dtype == np.float32 and scaler.mean_.dtype == np.float64
+    np.savez_compressed(os.path.join(OUT, "g9_scaler.npz"), **d)
+    print("g9_scaler.npz: scale_[3:8] =", scaler.scale_[3:8])
+
+
 def main():
+    if sys.argv[1:] == ["g9"]:               # the scaler golden needs scikit-learn only, not the reference checkout
+        os.makedirs(OUT, exist_ok=True)
+        return golden_scaler()
     torch.set_num_threads(4)
     torch.use_deterministic_algorithms(False)
     os.makedirs(OUT, exist_ok=True)
@@ -244,6 +267,7 @@ def main():
     d["pack_feat"], d["pack_seqs"] = feat, seqs
     d["pack_mc"] = utils.split_multi_channels(seqs, 2)
     np.savez_compressed(os.path.join(OUT, "g8_window_aug.npz"), **d)
+    golden_scaler()
     print("goldens written to", os.path.normpath(OUT))
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))/1e3:.1f} KB")

@@ -92,10 +92,12 @@ SIGNATURES = {
     "sed_pack_sequences": (_i, [_fp, _l, _i, _i, _i, _i, _fp, _stream]),
     "sed_col_mean_std_workspace_bytes": (_sz, [_i]),
     "sed_col_mean_std": (_i, [_fp, _l, _i, _fp, _fp, _fp, _stream]),
+    "sed_col_standardize": (_i, [_fp, _l, _i, _fp, _fp, _fp, _stream]),
     "sed_segment_counts": (_i, [_fp, _fp, _l, _i, _i, _f, _fp, _stream]),
     "sed_prof_enable": (_i, [C.c_uint]),
     "sed_prof_read": (_i, [_i, C.POINTER(_d), C.POINTER(_l), C.POINTER(_d)]),
     "sed_prof_tag_name": (C.c_char_p, [_i]),
+    "sed_prof_tag_count": (_i, []),
     "sed_net_out_shape": (_i, [C.POINTER(NetCfg), C.POINTER(_i), C.POINTER(_i)]),
     "sed_net_workspace_bytes": (_sz, [C.POINTER(NetCfg), _i]),
     "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _fp, _stream]),

@@ -74,4 +74,5 @@ extern "C" int sed_prof_read(int tag, double* total_ms, long* launches, double* 
     return 0;
 }
 
+extern "C" int sed_prof_tag_count(void) { return SED_K_COUNT; }
 extern "C" const char* sed_prof_tag_name(int tag) { return (tag >= 0 && tag < SED_K_COUNT) ? kNames[tag] : "?"; }

@@ -83,16 +83,22 @@ extern "C" int sed_pack_sequences(const float* feat, long N, int C, int F, int S
     return 0;
 }
 
-// per-column mean and population standard deviation (sklearn StandardScaler: ddof = 0, sigma 0 -> 1)
+// per-column mean and population standard deviation with sklearn StandardScaler's rules (feature.py:127-128;
+// sklearn/preprocessing/_data.py, utils/extmath.py:_incremental_mean_and_var): float64 accumulation, variance from the
+// CENTRED second pass  var = (sum d^2 - (sum d)^2 / N) / N  with d = x - mean, and a column whose variance is within the
+// rounding bound of that algorithm,  var <= N*eps*var + (N*mean*eps)^2  (_is_constant_feature), gets scale 1.
 #define CS_BLOCKS 256
-__global__ __launch_bounds__(256) void colstats_partial_k(const float* __restrict__ x, long N, int F, double* __restrict__ part) {
+template <bool CENTRED>
+__global__ __launch_bounds__(256) void colstats_partial_k(const float* __restrict__ x, long N, int F,
+                                                          const double* __restrict__ mean, double* __restrict__ part) {
     // block handles rows [r0, r1); thread (col, slice)
     const int nsl = 256 / F > 0 ? 256 / F : 1;
     const int col = threadIdx.x % F, sl = threadIdx.x / F;
     long per = (N + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
     double a = 0.0, q = 0.0;
+    const double mu = CENTRED ? mean[col] : 0.0;
     if (sl < nsl)
-        for (long r = r0 + sl; r < r1; r += nsl) { double v = x[r * F + col]; a += v; q += v * v; }
+        for (long r = r0 + sl; r < r1; r += nsl) { double v = (double)x[r * F + col] - mu; a += v; q += v * v; }
     __shared__ double s1[256], s2[256];
     s1[threadIdx.x] = a; s2[threadIdx.x] = q;
     __syncthreads();
@@ -103,28 +109,63 @@ __global__ __launch_bounds__(256) void colstats_partial_k(const float* __restric
         part[((size_t)blockIdx.x * 2 + 1) * F + threadIdx.x] = Q;
     }
 }
-__global__ void colstats_final_k(const double* __restrict__ part, int nb, long N, int F, float* mean, float* stdv) {
+__global__ void colstats_mean_k(const double* __restrict__ part, int nb, long N, int F, double* __restrict__ mean) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= F) return;
-    double A = 0.0, Q = 0.0;
-    for (int b = 0; b < nb; ++b) { A += part[((size_t)b * 2) * F + c]; Q += part[((size_t)b * 2 + 1) * F + c]; }
-    double m = A / (double)N, var = Q / (double)N - m * m;
+    double A = 0.0;
+    for (int b = 0; b < nb; ++b) A += part[((size_t)b * 2) * F + c];
+    mean[c] = A / (double)N;
+}
+__global__ void colstats_final_k(const double* __restrict__ part, int nb, long N, int F, const double* __restrict__ mean_d,
+                                 double* mean, double* stdv) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= F) return;
+    double D = 0.0, Q = 0.0;
+    for (int b = 0; b < nb; ++b) { D += part[((size_t)b * 2) * F + c]; Q += part[((size_t)b * 2 + 1) * F + c]; }
+    const double n = (double)N, m = mean_d[c];
+    double var = (Q - D * D / n) / n;
     if (var < 0.0) var = 0.0;
-    double sd = sqrt(var);
-    mean[c] = (float)m;
-    stdv[c] = sd == 0.0 ? 1.f : (float)sd;
+    const double eps = 2.220446049250313e-16, nme = n * m * eps;
+    const bool constant = var <= n * eps * var + nme * nme;
+    mean[c] = m;
+    stdv[c] = constant ? 1.0 : sqrt(var);
 }
 
-extern "C" size_t sed_col_mean_std_workspace_bytes(int F) { return (size_t)CS_BLOCKS * 2 * F * sizeof(double); }
+extern "C" size_t sed_col_mean_std_workspace_bytes(int F) { return ((size_t)CS_BLOCKS * 2 + 1) * F * sizeof(double); }
 
-extern "C" int sed_col_mean_std(const float* x, long N, int F, float* mean, float* stdv, void* workspace, void* stream) {
+extern "C" int sed_col_mean_std(const float* x, long N, int F, double* mean, double* stdv, void* workspace, void* stream) {
     SED_REQUIRE(x && mean && stdv && workspace && N > 0 && F > 0 && F <= 256, "col_mean_std: bad arguments (F <= 256)");
     hipStream_t s = as_stream(stream);
     int nb = N < CS_BLOCKS ? (int)N : CS_BLOCKS;
-    colstats_partial_k<<<nb, 256, 0, s>>>(x, N, F, (double*)workspace);
+    double* part = (double*)workspace;
+    double* mean_d = part + (size_t)CS_BLOCKS * 2 * F;
+    colstats_partial_k<false><<<nb, 256, 0, s>>>(x, N, F, nullptr, part);
     SED_LAUNCH_CHECK("colstats_partial");
-    colstats_final_k<<<cdiv(F, 64), 64, 0, s>>>((const double*)workspace, nb, N, F, mean, stdv);
+    colstats_mean_k<<<cdiv(F, 64), 64, 0, s>>>(part, nb, N, F, mean_d);
+    SED_LAUNCH_CHECK("colstats_mean");
+    colstats_partial_k<true><<<nb, 256, 0, s>>>(x, N, F, mean_d, part);
+    SED_LAUNCH_CHECK("colstats_partial_centred");
+    colstats_final_k<<<cdiv(F, 64), 64, 0, s>>>(part, nb, N, F, mean_d, mean, stdv);
     SED_LAUNCH_CHECK("colstats_final");
+    return 0;
+}
+
+// StandardScaler.transform (feature.py:128-129) on a float32 matrix: sklearn's in-place `X -= mean_; X /= scale_` with
+// float64 statistics rounds to float32 after EACH of the two steps; so does this.  In place allowed.
+__global__ __launch_bounds__(256) void col_standardize_k(const float* __restrict__ x, long n, int F, const double* __restrict__ mean,
+                                                         const double* __restrict__ stdv, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int c = (int)(i % F);
+        float d = (float)((double)x[i] - mean[c]);
+        out[i] = (float)((double)d / stdv[c]);
+    }
+}
+extern "C" int sed_col_standardize(const float* x, long N, int F, const double* mean, const double* stdv, float* out, void* stream) {
+    SED_REQUIRE(x && mean && stdv && out && N > 0 && F > 0, "col_standardize: bad arguments");
+    long n = N * F;
+    long nb = (n + 255) / 256;
+    col_standardize_k<<<(unsigned)(nb < 4096 ? nb : 4096), 256, 0, as_stream(stream)>>>(x, n, F, mean, stdv, out);
+    SED_LAUNCH_CHECK("col_standardize");
     return 0;
 }
 
@@ -138,17 +179,20 @@ __global__ void segment_counts_k(const float* __restrict__ pred, const float* __
                                  float thr, unsigned long long* __restrict__ out) {
     long bi = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long nceil = (rows + block - 1) / block, nfloor = rows / block;
-    unsigned long long c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[SED_SEGMENT_COUNTS] = {};
     if (bi < nceil) {
         long r0 = bi * block, r1 = r0 + block < rows ? r0 + block : rows;
         unsigned ob = 0, tb = 0;                                   // per-class block maxima as bit masks (K <= 32)
         for (long r = r0; r < r1; ++r) {
             unsigned fp = 0, fn = 0;
             for (int k = 0; k < K; ++k) {
-                bool o = pred[r * K + k] > thr, t = lab[r * K + k] == 1.f;
+                const float lv = lab[r * K + k];
+                bool o = pred[r * K + k] > thr, t = lv == 1.f;
                 ob |= (unsigned)o << k; tb |= (unsigned)t << k;
                 c[0] += (o && t); c[1] += t; c[2] += o;
                 fp += (o && !t); fn += (t && !o);
+                const bool t0 = lv >= 0.f && lv < 1.f, t1 = lv >= 1.f && lv < 2.f;    // uint8 truncation of the label
+                c[13] += (!o && t0); c[14] += (o && t0); c[15] += (!o && t1); c[16] += (o && t1);
             }
             c[3] += fp < fn ? fp : fn; c[4] += fn > fp ? fn - fp : 0; c[5] += fp > fn ? fp - fn : 0;
         }
@@ -157,7 +201,7 @@ __global__ void segment_counts_k(const float* __restrict__ pred, const float* __
         if (bi < nfloor) { c[9] += fp < fn ? fp : fn; c[10] += fn > fp ? fn - fp : 0; c[11] += fp > fn ? fp - fn : 0; c[12] += nref; }
     }
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
+    for (int i = 0; i < SED_SEGMENT_COUNTS; ++i) {
         unsigned long long v = c[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -166,13 +210,13 @@ __global__ void segment_counts_k(const float* __restrict__ pred, const float* __
 }
 
 extern "C" int sed_segment_counts(const float* pred, const float* lab, long rows, int K, int block, float threshold,
-                                  unsigned long long* counts13, void* stream) {
-    SED_REQUIRE(pred && lab && counts13 && rows > 0 && K > 0 && K <= 32 && block > 0, "segment_counts: bad arguments (K <= 32)");
+                                  unsigned long long* counts17, void* stream) {
+    SED_REQUIRE(pred && lab && counts17 && rows > 0 && K > 0 && K <= 32 && block > 0, "segment_counts: bad arguments (K <= 32)");
     hipStream_t s = as_stream(stream);
-    hipError_t e = hipMemsetAsync(counts13, 0, 13 * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(counts17, 0, SED_SEGMENT_COUNTS * sizeof(unsigned long long), s);
     if (e != hipSuccess) { sed_set_error("segment_counts: memset: %s", hipGetErrorString(e)); return (int)e; }
     long nceil = (rows + block - 1) / block;
-    segment_counts_k<<<cdiv(nceil, 256), 256, 0, s>>>(pred, lab, rows, K, block, threshold, counts13);
+    segment_counts_k<<<cdiv(nceil, 256), 256, 0, s>>>(pred, lab, rows, K, block, threshold, counts17);
     SED_LAUNCH_CHECK("segment_counts");
     return 0;
 }

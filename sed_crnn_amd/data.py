@@ -21,12 +21,24 @@ SEQ_LEN_IN, SEQ_LEN_OUT = 64, 8                       # train_constants.py:6-8
 TIME_MASK_W, FREQ_MASK_W, MASKS_PER_EX = 8, 8, 2      # train_constants.py:14-16
 
 
+def load_fold_npz(folder, fold_id):
+    """One fold pack ``mbe_mon_fold{n}.npz``: positional arrays arr_0..arr_3 = X_train [N,40], Y_train [N,1], X_test,
+    Y_test (written at feature.py:131-132, read at sed.py:119-123)."""
+    path = os.path.join(folder, f"mbe_mon_fold{fold_id}.npz")
+    with np.load(path, allow_pickle=False) as arr:
+        missing = [k for k in ("arr_0", "arr_1", "arr_2", "arr_3") if k not in arr.files]
+        if missing:
+            raise ValueError(f"{path}: not a fold pack (missing {missing}; feature.py:131-132 saves four positional arrays)")
+        fd = {"train_x": arr["arr_0"], "train_y": arr["arr_1"], "val_x": arr["arr_2"], "val_y": arr["arr_3"]}
+    for a, b in (("train_x", "train_y"), ("val_x", "val_y")):
+        if fd[a].shape[0] != fd[b].shape[0]:
+            raise ValueError(f"{path}: {a} has {fd[a].shape[0]} frames but {b} has {fd[b].shape[0]}")
+    return fd
+
+
 def load_all_npz(folder):
-    folds = {}
-    for i in range(1, 5):
-        arr = np.load(os.path.join(folder, f"mbe_mon_fold{i}.npz"), allow_pickle=False)
-        folds[i] = {"train_x": arr["arr_0"], "train_y": arr["arr_1"], "val_x": arr["arr_2"], "val_y": arr["arr_3"]}
-    return folds
+    """sed.py:115-125: all four folds, keyed 1..4"""
+    return {i: load_fold_npz(folder, i) for i in range(1, 5)}
 
 
 def find_clean_negatives(lab, seq_len=SEQ_LEN_IN):
@@ -126,13 +138,24 @@ class GpuWindowLoader:
 
 
 def standard_scaler_fit(x):
-    """per-column (mean, sigma) of a device matrix [N, F]; sklearn StandardScaler semantics (ddof 0, sigma 0 -> 1)"""
+    """per-column (mean, sigma) of a device matrix [N, F] with sklearn StandardScaler's rules: float64 accumulation,
+    ddof 0, scale 1 for a (numerically) constant column — pinned by tests/golden/g9_scaler.npz"""
     x = x.contiguous().float()
     N, F = x.shape
-    mean, std = torch.empty(F, device=x.device), torch.empty(F, device=x.device)
+    mean, std = (torch.empty(F, device=x.device, dtype=torch.float64) for _ in range(2))      # like sklearn's mean_ / scale_
     ws = torch.empty(lib().sed_col_mean_std_workspace_bytes(F) // 4, device=x.device)
     check(lib().sed_col_mean_std(ptr(x), N, F, ptr(mean), ptr(std), ptr(ws), stream_ptr()), "sed_col_mean_std")
     return mean, std
+
+
+def standard_scaler_transform(x, mean, std, out=None):
+    """(x - mean) / sigma per column on the device (StandardScaler.transform, feature.py:128-129); ``out=x`` works in place"""
+    x = x.contiguous().float()
+    N, F = x.shape
+    out = torch.empty_like(x) if out is None else out
+    check(lib().sed_col_standardize(ptr(x), N, F, ptr(mean.to(x.device).contiguous().double()),
+                                    ptr(std.to(x.device).contiguous().double()), ptr(out), stream_ptr()), "sed_col_standardize")
+    return out
 
 
 def pack_sequences(feat, seq_len, n_channels=1, time_last=True):

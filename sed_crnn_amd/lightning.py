@@ -1,22 +1,25 @@
-"""Mirror of the reference LightningModule (crnn_lightning.py:79-200) and of the Trainer settings of
-train_lightning.py:27-63, running on the HIP path.
+"""The reference LightningModule's API surface (crnn_lightning.py:79-200) and the Trainer settings of
+train_lightning.py:27-63, on the HIP path.
 
-``CRNNLightning(fold_id, art_dir, lr=1e-3, weight_decay=1e-4, dropout=0.4)`` keeps the reference's hooks, log keys
-(``train_loss``, ``val_loss``, ``val_er_1s``, ``val_f1_1s``), public dicts (``_buf``, ``track``) and
-``configure_optimizers()`` contract.  When ``pytorch_lightning`` is importable the class derives from
-``pl.LightningModule`` and can be handed to ``pl.Trainer``; it is absent from this image, so ``fit_lightning`` below
-reproduces what the reference's Trainer does for this path (fit/validate epochs, gradient_clip_val=1.0,
-ReduceLROnPlateau on ``val_loss``, EarlyStopping(patience) and per-epoch checkpoints named
-``epoch{epoch:03d}-valer{val_er_1s:.3f}`` + ``last``), without Lightning.
+``CRNNLightning(fold_id, art_dir, lr=1e-3, weight_decay=1e-4, dropout=0.4)`` keeps what callbacks and users bind to:
+the hook names, the log keys (``train_loss``, ``val_loss``, ``val_er_1s``, ``val_f1_1s``), the public dicts ``_buf``
+and ``track``, the ``_aggregate(mode)`` result keys and the ``configure_optimizers()`` contract.  The bodies are not the
+reference's: an epoch is aggregated from 17 integer counts computed on the device (``sed_segment_counts``) instead of
+copying every prediction to the host (crnn_lightning.py:102-129), and both step hooks and both epoch-end hooks go
+through one helper each.  The matplotlib dashboard (crnn_lightning.py:131-154) is out of scope.
+
+When ``pytorch_lightning`` is importable the class derives from ``pl.LightningModule`` and can be handed to
+``pl.Trainer``; it is absent from this image, so ``fit_lightning`` reproduces what the reference's Trainer does for this
+path (fit/validate epochs, gradient_clip_val=1.0, ReduceLROnPlateau on ``val_loss``, EarlyStopping(patience) and
+per-epoch checkpoints named ``epoch{epoch:03d}-valer{val_er_1s:.3f}`` + ``last``), without Lightning.
 """
 import os
 import types
 
-import numpy as np
 import torch
 import torch.nn as nn
 
-from . import metrics
+from . import metrics, ops
 from .losses import FocalBCELoss
 from .model import LightningTimePooledCRNN
 from .optim import FusedAdam
@@ -42,6 +45,10 @@ except Exception:                             # ModuleNotFoundError here
             self.logged[name] = value
 
 
+_MODES = {"train": "tr", "val": "val"}                                                  # _buf key -> track suffix
+_TRACKED = {"loss": "loss", "f1_1s": "f1_1s", "er_1s": "er_1s", "f1_frame": "f1_fr", "er_frame": "er_fr"}   # result key -> track stem
+
+
 class CRNNLightning(_Base):
     def __init__(self, fold_id: int, art_dir: str, lr=1e-3, weight_decay=1e-4, dropout=0.4, **model_kw):
         super().__init__()
@@ -52,102 +59,77 @@ class CRNNLightning(_Base):
         self.art_dir = art_dir
         self.model = LightningTimePooledCRNN(dropout, **model_kw)
         self.loss_fn = FocalBCELoss()
-        self._buf = {m: {"preds": [], "trues": [], "losses": []} for m in ["train", "val"]}
-        self.track = {k: [] for k in [
-            "loss_tr", "loss_val", "f1_1s_tr", "f1_1s_val", "er_1s_tr", "er_1s_val",
-            "f1_fr_tr", "f1_fr_val", "er_fr_tr", "er_fr_val"]}
+        self._buf = {mode: dict(preds=[], trues=[], losses=[]) for mode in _MODES}
+        self.track = {f"{stem}_{sfx}": [] for stem in _TRACKED.values() for sfx in _MODES.values()}
+        self._last = {}
 
     def forward(self, x):
         return self.model(x)
 
-    # ── helpers (crnn_lightning.py:97-129) ──
+    # ── one step / one epoch end, shared by the train and val hooks ──
     def _collect(self, logits, y, loss, mode):
-        from . import ops
-        self._buf[mode]["preds"].append(ops.sigmoid(logits.detach().contiguous()))     # stays on the device
-        self._buf[mode]["trues"].append(y)
-        self._buf[mode]["losses"].append(loss.detach())
+        """keep this batch's probabilities, labels and loss ON THE DEVICE until the epoch ends"""
+        buf = self._buf[mode]
+        buf["preds"].append(ops.sigmoid(logits.detach().contiguous()))
+        buf["trues"].append(y)
+        buf["losses"].append(loss.detach().reshape(1))
 
     def _aggregate(self, mode):
-        p_t = torch.cat(self._buf[mode]["preds"])
-        t_t = torch.cat(self._buf[mode]["trues"])
-        loss = torch.stack([l.reshape(()) for l in self._buf[mode]["losses"]]).mean().item()
-        for k in self._buf[mode]:
-            self._buf[mode][k].clear()
-        p, t = p_t.detach().cpu().numpy(), t_t.detach().cpu().numpy()          # one D2H per epoch
-        p_bin, t_bin = (p > 0.5).astype(np.uint8), t.astype(np.uint8)
-        tn = np.logical_and(p_bin == 0, t_bin == 0).sum()
-        fp = np.logical_and(p_bin == 1, t_bin == 0).sum()
-        fn = np.logical_and(p_bin == 0, t_bin == 1).sum()
-        tp = np.logical_and(p_bin == 1, t_bin == 1).sum()
-        return dict(loss=loss,
-                    f1_frame=metrics.f1_overall_framewise(p_bin, t_bin), er_frame=metrics.er_overall_framewise(p_bin, t_bin),
-                    f1_1s=metrics.f1_overall_1sec(p_bin, t_bin, FPS_OUT), er_1s=metrics.er_overall_1sec(p_bin, t_bin, FPS_OUT),
-                    cm=np.array([[tn, fp], [fn, tp]]))
+        """-> dict(loss, f1_frame, er_frame, f1_1s, er_1s, cm) like crnn_lightning.py:102-129, from device-side counts:
+        threshold > 0.5, labels truncated to uint8, 1-second blocks of FPS_OUT rows over the concatenated windows."""
+        buf = self._buf[mode]
+        counts = metrics.device_counts(torch.cat(buf["preds"]), torch.cat(buf["trues"]), FPS_OUT, 0.5)
+        loss = torch.cat(buf["losses"]).mean()
+        for lst in buf.values():
+            lst.clear()
+        s = metrics.scores_from_counts(counts.cpu().tolist())          # 17 integers + 1 float cross PCIe
+        return dict(loss=loss.item(), f1_frame=s["f1_overall_framewise"], er_frame=s["er_overall_framewise"],
+                    f1_1s=s["f1_overall_1sec"], er_1s=s["er_overall_1sec"], cm=s["cm"])
 
-    def _plot_epoch(self, epoch, tr, val):
-        """2x3 dashboard of crnn_lightning.py:131-154 (loss / F1 / ER curves + the two confusion matrices)."""
-        try:
-            import matplotlib
-            matplotlib.use("Agg")
-            import matplotlib.pyplot as plt
-        except Exception:                     # plotting is optional plumbing, never part of the compute path
-            return None
-        os.makedirs(self.art_dir, exist_ok=True)
-        fig, ax = plt.subplots(2, 3, figsize=(14, 6))
-        for a, (k, title) in zip([ax[0, 0], ax[0, 1], ax[0, 2], ax[1, 2]],
-                                 [("loss", "Focal Loss"), ("f1_1s", "F1 (1 s)"), ("er_1s", "ER (1 s)"), ("f1_fr", "F1 (frame)")]):
-            a.plot(self.track[f"{k}_tr"], label="train")
-            a.plot(self.track[f"{k}_val"], label="val")
-            a.set_title(title); a.set_xlabel("Epoch"); a.grid(); a.legend()
-        for a, (m, title) in zip([ax[1, 0], ax[1, 1]], [(tr["cm"], f"Train CM (e{epoch})"), (val["cm"], f"Val CM (e{epoch})")]):
-            a.imshow(m, cmap="Blues")
-            for i in range(2):
-                for j in range(2):
-                    a.text(j, i, f"{m[i, j]}", ha="center", va="center")
-            a.set_xticks([0, 1]); a.set_yticks([0, 1]); a.set_xlabel("Pred"); a.set_ylabel("True"); a.set_title(title)
-        out = os.path.join(self.art_dir, f"metrics_fold{self.hparams.fold_id}.png")
-        fig.tight_layout(); fig.savefig(out); plt.close(fig)
-        return out
-
-    # ── Lightning hooks (crnn_lightning.py:157-193) ──
-    def training_step(self, batch, _):
+    def _step(self, batch, mode):
         x, y = batch
         logits = self(x)
         loss = self.loss_fn(logits, y)
-        self._collect(logits, y, loss, "train")
-        self.log("train_loss", loss, on_epoch=True, prog_bar=True)
+        self._collect(logits, y, loss, mode)
+        self.log(f"{mode}_loss", loss, on_epoch=True, prog_bar=True)
         return loss
 
-    def on_train_epoch_end(self):
-        tr = self._aggregate("train")
-        self.track["loss_tr"].append(tr["loss"])
-        self.track["f1_1s_tr"].append(tr["f1_1s"]); self.track["er_1s_tr"].append(tr["er_1s"])
-        self.track["f1_fr_tr"].append(tr["f1_frame"]); self.track["er_fr_tr"].append(tr["er_frame"])
-        self._last_train = tr
+    def _end_epoch(self, mode):
+        res = self._aggregate(mode)
+        for key, stem in _TRACKED.items():
+            self.track[f"{stem}_{_MODES[mode]}"].append(res[key])
+        self._last[mode] = res
+        return res
 
-    def validation_step(self, batch, _):
-        x, y = batch
-        logits = self(x)
-        loss = self.loss_fn(logits, y)
-        self._collect(logits, y, loss, "val")
-        self.log("val_loss", loss, on_epoch=True, prog_bar=True)
+    # ── Lightning hooks (names and log keys of crnn_lightning.py:157-193) ──
+    def training_step(self, batch, batch_idx):
+        return self._step(batch, "train")
+
+    def validation_step(self, batch, batch_idx):
+        self._step(batch, "val")
+
+    def on_train_epoch_end(self):
+        self._end_epoch("train")
 
     def on_validation_epoch_end(self):
-        val = self._aggregate("val")
-        self.track["loss_val"].append(val["loss"])
-        self.track["f1_1s_val"].append(val["f1_1s"]); self.track["er_1s_val"].append(val["er_1s"])
-        self.track["f1_fr_val"].append(val["f1_frame"]); self.track["er_fr_val"].append(val["er_frame"])
+        val = self._end_epoch("val")
         self.log("val_er_1s", val["er_1s"], prog_bar=True)
         self.log("val_f1_1s", val["f1_1s"], prog_bar=True)
-        if not hasattr(self, "_last_train"):
-            self._last_train = val.copy()
-        self._last_val = val
-        self._plot_epoch(self.current_epoch, self._last_train, val)
+        self._last.setdefault("train", dict(val))          # Lightning's sanity-check validation runs before any training
+
+    @property
+    def _last_train(self):
+        return self._last["train"]
+
+    @property
+    def _last_val(self):
+        return self._last["val"]
 
     def configure_optimizers(self):
-        opt = FusedAdam(self.parameters(), lr=self.hparams.lr, weight_decay=self.hparams.weight_decay)
-        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=.5, patience=10)
-        return {"optimizer": opt, "lr_scheduler": {"scheduler": sched, "monitor": "val_loss"}}
+        hp = self.hparams
+        opt = FusedAdam(self.parameters(), lr=hp.lr, weight_decay=hp.weight_decay)       # coupled L2, like optim.Adam
+        plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="min", factor=0.5, patience=10)
+        return dict(optimizer=opt, lr_scheduler=dict(scheduler=plateau, monitor="val_loss"))
 
 
 def fit_lightning(module, train_loader, val_loader, max_epochs=200, early_stop=20, gradient_clip_val=1.0,
@@ -164,16 +146,16 @@ def fit_lightning(module, train_loader, val_loader, max_epochs=200, early_stop=2
     for epoch in range(max_epochs):
         module.current_epoch = epoch
         module.train()
-        for xb, yb in train_loader:
+        for i, (xb, yb) in enumerate(train_loader):
             opt.zero_grad()
-            loss = module.training_step((xb.to(device), yb.to(device).float()), 0)
+            loss = module.training_step((xb.to(device), yb.to(device).float()), i)
             loss.backward()
             opt.step()
         module.on_train_epoch_end()
         module.eval()
         with torch.no_grad():
-            for xb, yb in val_loader:
-                module.validation_step((xb.to(device), yb.to(device).float()), 0)
+            for i, (xb, yb) in enumerate(val_loader):
+                module.validation_step((xb.to(device), yb.to(device).float()), i)
         module.on_validation_epoch_end()
         val = module._last_val
         sched.step(val["loss"])

@@ -72,21 +72,29 @@ def compute_scores(pred, y, frames_in_1_sec=50):
             "er_overall_1sec": er_overall_1sec(pred, y, frames_in_1_sec)}
 
 
+N_COUNTS = 17                  # SED_SEGMENT_COUNTS of include/sedcrnn.h
+
+
 def device_counts(pred, y, frames_in_1_sec=50, threshold=0.5):
-    """13 integer counts of the thresholded predictions, computed on the GPU (one kernel, 104-byte result):
-    frame-wise TP,Nref,Nsys,S,D,I | TP,Nref,Nsys over ceil blocks | S,D,I,Nref over floor blocks."""
+    """17 integer counts of the thresholded predictions, computed on the GPU (one kernel, 136-byte result):
+    frame-wise TP,Nref,Nsys,S,D,I | TP,Nref,Nsys over ceil blocks | S,D,I,Nref over floor blocks | tn,fp,fn,tp.
+    ``pred``/``y`` are device tensors [..., K] of probabilities and 0/1 labels; rows are taken in storage order, i.e. the
+    windows of an epoch concatenated (blocks straddle window boundaries exactly as metrics.py:46-68 does)."""
     import torch
     from ._lib import check, lib, ptr, stream_ptr
     p = pred.reshape(-1, pred.shape[-1]).contiguous().float()
     t = y.reshape(-1, y.shape[-1]).contiguous().float()
-    out = torch.empty(13, dtype=torch.int64, device=p.device)
+    if p.shape != t.shape:
+        raise ValueError(f"predictions {tuple(pred.shape)} and labels {tuple(y.shape)} differ in shape")
+    out = torch.empty(N_COUNTS, dtype=torch.int64, device=p.device)
     check(lib().sed_segment_counts(ptr(p), ptr(t), p.shape[0], p.shape[1], int(frames_in_1_sec), float(threshold), ptr(out),
                                    stream_ptr()), "sed_segment_counts")
     return out
 
 
 def scores_from_counts(c):
-    """the reference's float64 formulas (metrics.py:25-29,43-44) applied to the integer counts"""
+    """the reference's float64 formulas (metrics.py:25-29,43-44) applied to the integer counts; also the 2x2 confusion
+    matrix [[tn, fp], [fn, tp]] of crnn_lightning.py:115-119 when the counts carry it"""
     c = [int(v) for v in c]
 
     def f1(tp, nref, nsys):
@@ -96,12 +104,15 @@ def scores_from_counts(c):
     def er(s_, d, i, nref):
         with np.errstate(divide="ignore", invalid="ignore"):
             return np.float64(s_ + d + i) / (np.float64(nref) + 0.0)
-    return {"f1_overall_framewise": f1(c[0], c[1], c[2]), "er_overall_framewise": er(c[3], c[4], c[5], c[1]),
-            "f1_overall_1sec": f1(c[6], c[7], c[8]), "er_overall_1sec": er(c[9], c[10], c[11], c[12])}
+    out = {"f1_overall_framewise": f1(c[0], c[1], c[2]), "er_overall_framewise": er(c[3], c[4], c[5], c[1]),
+           "f1_overall_1sec": f1(c[6], c[7], c[8]), "er_overall_1sec": er(c[9], c[10], c[11], c[12])}
+    if len(c) >= 17:
+        out["cm"] = np.array([[c[13], c[14]], [c[15], c[16]]])
+    return out
 
 
 def compute_scores_device(pred, y, frames_in_1_sec=50, threshold=0.5):
     """compute_scores(pred > threshold, y, frames_in_1_sec) for device tensors of PROBABILITIES, without copying the
-    predictions to the host (13 integers come back instead)."""
+    predictions to the host (17 integers come back instead)."""
     s = scores_from_counts(device_counts(pred, y, frames_in_1_sec, threshold).cpu().tolist())
     return {"f1_overall_1sec": s["f1_overall_1sec"], "er_overall_1sec": s["er_overall_1sec"]}

@@ -12,6 +12,7 @@ the HIP library or a GPU tensor the call raises.
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -20,6 +21,18 @@ from . import _lib
 from ._lib import NetCfg, NetParams, check, lib
 
 _MASK64 = (1 << 64) - 1
+_ARENA_OWNERS = weakref.WeakValueDictionary()       # storage address of a parameter arena -> the HipCRNN that owns it
+
+
+def arena_owner(param):
+    """the HipCRNN whose flat arena ``param`` is a view of, or None"""
+    try:
+        m = _ARENA_OWNERS.get(param.untyped_storage().data_ptr())
+    except Exception:
+        return None
+    if m is not None and any(q is param for q in m._arena_params):
+        return m
+    return None
 
 
 # ───────────────────────── parameter holders (same names / init as torch.nn) ─────────────────────────
@@ -97,11 +110,20 @@ class LinearParams(nn.Module):
 
 # ───────────────────────── autograd bridge ─────────────────────────
 class _NetFn(torch.autograd.Function):
+    """forward/backward of the whole network.  The parameters are passed only so that autograd sees the dependency.
+
+    Gradient hand-over, per parameter p with arena view g (the plan always WRITES the arena, it never accumulates):
+      * p.grad is already the arena view (``bind_flat_grads()`` / ``FusedAdam.attach``): the gradient is in place, autograd
+        gets None (returning g as well would make AccumulateGrad add it to itself: 2g);
+      * bound mode and p.grad is None (after ``zero_grad(set_to_none=True)``): p.grad is pointed at the view again;
+      * otherwise autograd gets the view and applies torch's own rule (install a copy, or ``p.grad += g``).
+    torch's accumulate-until-zero_grad semantics are kept in bound mode too: if a backward already ran since the last
+    zero_grad, the previous arena content is added back after the plan has overwritten it."""
+
     @staticmethod
     def forward(ctx, net, x, *params):
         logits = net._run_forward(x, training=True)
-        ctx.net, ctx.ticket, ctx.nparams = net, net._ticket, len(params)
-        ctx.save_for_backward(x)
+        ctx.net, ctx.ticket = net, net._ticket
         return logits
 
     @staticmethod
@@ -110,11 +132,24 @@ class _NetFn(torch.autograd.Function):
         if ctx.ticket != net._ticket:
             raise RuntimeError("sed_crnn_amd: the activations of this forward were overwritten by a later "
                                "training forward of the same module; call backward() before the next forward()")
-        (x,) = ctx.saved_tensors
-        net._run_backward(x, dlogits.contiguous())
-        accumulate = any(p.grad is not None for p in net._arena_params)
-        grads = [g.clone() if accumulate else g for g in net._grad_views]
-        return (None, None) + tuple(grads)
+        params, views = net._arena_params, net._grad_views
+        aliased = [p.grad is not None and p.grad.data_ptr() == g.data_ptr() for p, g in zip(params, views)]
+        carry = net._arena_grad.clone() if (net._arena_dirty and any(aliased)) else None
+        net._run_backward(None, dlogits.contiguous())
+        if carry is not None:                      # second backward without zero_grad: accumulate like torch would
+            mask = net._alias_mask(aliased)
+            net._arena_grad.add_(carry * mask if mask is not None else carry)
+        net._arena_dirty = True
+        out = []
+        for p, g, al in zip(params, views, aliased):
+            if al:
+                out.append(None)
+            elif net._bound_grads and p.grad is None:
+                p.grad = g
+                out.append(None)
+            else:
+                out.append(g)
+        return (None, None) + tuple(out)
 
 
 class HipCRNN(nn.Module):
@@ -135,10 +170,14 @@ class HipCRNN(nn.Module):
             f //= pf
         self.flat_features = conv_channels[-1] * f
         self.time_factor = math.prod(pt for _, pt in self.pools)
+        self._last = None
         self.overlap_wgrad = True        # BN backward of block l-1 on an auxiliary stream beside block l's weight gradient
         self._sync_bn, self._sync_group = False, None
         self._aux_stream = None
         self._ticket = 0
+        self._bound_grads = False       # p.grad are the arena views (bind_flat_grads / FusedAdam.attach)
+        self._arena_dirty = False       # a backward has written the arena since the last zero_grad
+        self._ws_pinned = set()         # workspace keys a captured hipGraph points into: never evicted
         self._seed_counter = 0
         self._nbt_pending = 0
         self._ws = {}
@@ -188,10 +227,16 @@ class HipCRNN(nn.Module):
                 p.grad = None
         assert len(order) == len(list(self.parameters())), "every parameter must have a role"
         self._arena, self._arena_grad = flat, flat_g
+        _ARENA_OWNERS[flat.untyped_storage().data_ptr()] = self      # lets FusedAdam(model.parameters()) find the arena
         self._arena_params, self._grad_views, self._arena_offsets = order, views, offs
         self._stage_ends = stage_ends          # arena slice [stage_ends[s-1], stage_ends[s]) = backward stage s
         self._structs = None
         self._ws = {}
+        self._ws_pinned = set()
+        self._arena_dirty = False
+        self._last = None
+        if self._bound_grads:
+            self.bind_flat_grads()
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
@@ -236,9 +281,25 @@ class HipCRNN(nn.Module):
         return out
 
     def bind_flat_grads(self):
-        """Point every p.grad at its arena view (what the fused optimiser / all-reduce operate on)."""
+        """Point every p.grad at its arena view (what the fused optimiser / all-reduce operate on) and keep it so: after a
+        ``zero_grad(set_to_none=True)`` the next backward binds them again."""
+        self._bound_grads = True
         for p, g in zip(self._arena_params, self._grad_views):
             p.grad = g
+
+    def zero_grad(self, set_to_none=True):
+        self._arena_dirty = False
+        return super().zero_grad(set_to_none)
+
+    def _alias_mask(self, aliased):
+        """1 on the arena elements whose parameter's .grad is the arena view, 0 elsewhere (None = all of them)"""
+        if all(aliased):
+            return None
+        m = torch.zeros_like(self._arena_grad)
+        for p, o, al in zip(self._arena_params, self._arena_offsets, aliased):
+            if al:
+                m[o:o + p.numel()] = 1.0
+        return m
 
     # ── C structs ──
     def _cfg(self, B, T):
@@ -293,10 +354,19 @@ class HipCRNN(nn.Module):
             if nbytes == 0:
                 check(-1, "sed_net_workspace_bytes")
             ws = torch.empty(nbytes // 4 + 64, device=self._arena.device, dtype=torch.float32)
-            if len(self._ws) >= 4:
-                self._ws.clear()
+            while len(self._ws) - len(self._ws_pinned) >= 4:          # drop the oldest shape no captured graph points into
+                victim = next((k for k in self._ws if k not in self._ws_pinned), None)
+                if victim is None:
+                    break
+                if self._last is not None and self._last[1] is self._ws[victim]:
+                    self._last = None
+                del self._ws[victim]
             self._ws[key] = ws
         return ws
+
+    def pin_workspace(self, B, T, training=True):
+        """A captured hipGraph holds raw pointers into the workspace of this shape: keep it for the module's lifetime."""
+        self._ws_pinned.add((int(B), int(T), bool(training)))
 
     def _check_input(self, x):
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
@@ -308,14 +378,24 @@ class HipCRNN(nn.Module):
             raise ValueError(f"expected input [B,{self.in_channels},{self.n_mels},T], got {tuple(x.shape)}")
         if x.shape[3] % self.time_factor:
             raise ValueError(f"T={x.shape[3]} must be a multiple of {self.time_factor}")
+        if not (x.dtype.is_floating_point or x.dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64)):
+            raise ValueError(f"unsupported input dtype {x.dtype}")
+
+    @staticmethod
+    def _rank_salt():
+        """data-parallel ranks must not drop the same positions of their shards: mix the rank into the dropout seed"""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank() * 0xA24BAED4963EE407
+        return 0
 
     def _graph_seed(self):
         # constant base seed of a captured step; the per-step variation comes from the device-side salt
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x51ED270B) & _MASK64
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x51ED270B + self._rank_salt()) & _MASK64
 
     def _next_seed(self):
         self._seed_counter += 1
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_counter * 0xD1B54A32D192ED03) & _MASK64
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._seed_counter * 0xD1B54A32D192ED03 + self._rank_salt()) & _MASK64
 
     # ── synchronised BatchNorm for data-parallel training (SURVEY 8e) ──
     def enable_sync_bn(self, process_group=None, enabled=True):
@@ -342,7 +422,7 @@ class HipCRNN(nn.Module):
         """step_state: optional device tensor {dropout salt, optimiser step} (uint64[2]) read by the kernels instead of a
         host-side seed, which makes the launch sequence replayable as a hipGraph (trainer.FusedTrainStep(graph=True))."""
         self._check_input(x)
-        x = x.contiguous().float()
+        x = x.detach().contiguous().float()        # the kernels read dense fp32 [B,Cin,F,T]; backward re-reads THIS tensor
         B, _, _, T = x.shape
         cfg = self._cfg(B, T)
         P, _ = self._param_structs()
@@ -352,7 +432,7 @@ class HipCRNN(nn.Module):
             self._ticket += 1
             self._seed = self._next_seed() if step_state is None else self._graph_seed()
             self._nbt_pending += 1
-            self._last = (cfg, ws)
+            self._last = (cfg, ws, x)
             self._last_state = step_state
         seed = self._seed if training else 0
         world = self._sync_world() if training else 1
@@ -371,7 +451,11 @@ class HipCRNN(nn.Module):
         return logits
 
     def _run_backward(self, x, dlogits, stage_begin=0, stage_end=None):
-        cfg, ws = self._last
+        """``x`` is ignored (kept for call compatibility): the first block re-reads the network input, and it must be
+        the converted (contiguous fp32) tensor the forward ran on, which the forward kept."""
+        if self._last is None:
+            raise RuntimeError("sed_crnn_amd: backward without a training forward (or its workspace was evicted)")
+        cfg, ws, x = self._last
         P, G = self._param_structs()
         if stage_end is None:
             stage_end = len(self.conv_channels) + 1

@@ -183,6 +183,12 @@ def gru_seq_bwd(dout, saved, whh, want_bias=False):
 
 def loss_fwd_bwd(logits, targets, kind="bce", alpha=0.25, gamma=2.0, reduction="mean"):
     """-> (loss scalar tensor, dlogits, probs)"""
+    if kind not in ("bce", "focal"):
+        raise ValueError(f"loss kind must be 'bce' or 'focal', got {kind!r}")
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"reduction must be 'mean' or 'sum' (the fused loss returns a scalar), got {reduction!r}")
+    if logits.shape != targets.shape:
+        raise ValueError(f"logits {tuple(logits.shape)} and targets {tuple(targets.shape)} differ in shape")
     n = logits.numel()
     loss = torch.empty(1, device=logits.device)
     d = torch.empty_like(logits)

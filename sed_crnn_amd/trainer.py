@@ -20,7 +20,7 @@ class FusedTrainStep:
         self.loss_kind, self.alpha, self.gamma = loss, focal_alpha, focal_gamma
         self.clip_norm = clip_norm
         self.t = 0
-        p = model.flat_parameters()
+        p = self._p = model.flat_parameters()
         self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
         if distributed is None:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
@@ -35,6 +35,9 @@ class FusedTrainStep:
 
     def step(self, x, y):
         """x [B,Cin,F,T], y [B,T',K] on the device -> (loss [1], probs [B,T',K]) device tensors (no sync)."""
+        if self.model.flat_parameters() is not self._p:
+            raise RuntimeError("FusedTrainStep: the model's arenas were rebuilt (model.to(...) / copy) after the trainer was "
+                               "created; its Adam moments, captured graphs and all-reduce buckets point at the old ones")
         if self.graph:
             return self._step_graph(x, y)
         return self._step_eager(x, y)
@@ -54,8 +57,9 @@ class FusedTrainStep:
             with torch.cuda.graph(g):
                 out = self._step_eager(sx, sy, state=self._state)
             self.t -= 1                                          # the capture pass enqueued nothing
-            ent = self._graphs[key] = (g, sx, sy, out)
-        g, sx, sy, out = ent
+            self.model.pin_workspace(sx.shape[0], sx.shape[3], True)   # the graph holds raw pointers into that workspace
+            ent = self._graphs[key] = (g, sx, sy, out, self.model._last[1])
+        g, sx, sy, out, _ws = ent
         sx.copy_(x)
         sy.copy_(y)
         g.replay()

@@ -84,10 +84,10 @@ def test_standard_scaler_fit_and_fused_transform(data):
     x = (rng.standard_normal((5000, 40)) * rng.uniform(0.5, 3, 40) + rng.uniform(-5, 5, 40)).astype(np.float32)
     x[:, 7] = 2.5                                                        # constant column: sigma -> 1
     mean, std = data.standard_scaler_fit(torch.from_numpy(x).cuda())
-    np.testing.assert_allclose(mean.cpu().numpy(), x.astype(np.float64).mean(0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(mean.cpu().numpy(), x.astype(np.float64).mean(0), rtol=1e-12, atol=1e-12)
     ref_sd = x.astype(np.float64).std(0)
     ref_sd[7] = 1.0
-    np.testing.assert_allclose(std.cpu().numpy(), ref_sd, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(std.cpu().numpy(), ref_sd, rtol=1e-9)
 
 
 def test_run_epoch_on_gpu_loader(data):

@@ -1,0 +1,287 @@
+"""GPU tests of the fit-loop rows: the 4-fold driver on real fold packs, the device-side epoch
+tally, the StandardScaler kernels against the sklearn golden, and the autograd / optimiser hand-over cases the round-1
+advisor found (non-contiguous or float64 input, arena-bound gradients, one Adam moment store)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sed():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sed_crnn_amd
+    return sed_crnn_amd
+
+
+def _write_pack(folder, fold, n_train=700, n_val=400):
+    """a tiny learnable fold pack in the layout feature.py:131-132 writes (positional arr_0..arr_3)"""
+    rng = np.random.default_rng(100 + fold)
+
+    def split(n):
+        x = rng.standard_normal((n, 40)).astype(np.float32)
+        y = np.zeros((n, 1), np.float32)
+        for s in rng.integers(70, n - 70, size=6):
+            y[s:s + 5] = 1
+            x[s:s + 5, 8:16] += 2.5                       # a hit is audible: energy in a mel band
+        return x, y
+    xtr, ytr = split(n_train)
+    xva, yva = split(n_val)
+    np.savez(os.path.join(folder, f"mbe_mon_fold{fold}.npz"), xtr, ytr, xva, yva)
+    return xva, yva
+
+
+def test_fit_folds_trains_four_folds_saves_best_er_checkpoints_the_oracle_can_load(sed, tmp_path):
+    """sed.py:144-207 end to end on four tiny fold packs: per fold 3 epochs, best-ER checkpoint `best_fold{n}.pt`, mean ER.
+    The saved bare state_dict must load into the ORACLE net and reproduce the HIP model's eval probabilities."""
+    from oracle import crnn_ref
+    from sed_crnn_amd import data
+    cache, art = tmp_path / "cache", tmp_path / "art"
+    cache.mkdir()
+    val = {f: _write_pack(str(cache), f) for f in range(1, 5)}
+    torch.manual_seed(5)
+    kw = dict(conv_channels=16, dropout=0.1, gru_hidden=16)
+    seen = []
+    res = sed.fit_folds(str(cache), str(art), model_factory=lambda: sed.TimePooledCRNN(**kw), batch_size=8, max_epochs=3,
+                        early_stop=40, lr=2e-3, seed=3, on_epoch=lambda f, rec: seen.append((f, rec["epoch"])))
+    assert sorted(res["folds"]) == [1, 2, 3, 4] and len(res["error_rates"]) == 4
+    assert seen == [(f, e) for f in range(1, 5) for e in (1, 2, 3)]
+    finite = [e for e in res["error_rates"] if np.isfinite(e)]
+    assert res["mean_er"] == pytest.approx(float(np.mean(res["error_rates"])), nan_ok=True) and len(finite) >= 1
+    for f, r in res["folds"].items():
+        hist = r["history"]
+        assert len(hist) == 3 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist)
+        ers = [h["val_er"] for h in hist]
+        best = min((e for e in ers if not np.isnan(e)), default=float("inf"))
+        assert r["best_er"] == best
+        if np.isfinite(best):
+            assert r["best_epoch"] == 1 + ers.index(best)                      # the FIRST epoch that reached it (strict <)
+            assert r["checkpoint"] == str(art / f"best_fold{f}.pt") and os.path.exists(r["checkpoint"])
+    # a checkpoint is the reference's format: load it into the oracle net and into a fresh HIP net
+    f = next(f for f, r in res["folds"].items() if np.isfinite(r["best_er"]))
+    sd = torch.load(art / f"best_fold{f}.pt", weights_only=True)
+    ref = crnn_ref.SedNetRef(**kw)
+    ref.load_state_dict(sd)
+    ref.eval()
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(sd)
+    m.cuda().eval()
+    xva, yva = val[f]
+    ds = data.HitWindowSet(xva, yva, seed=1)
+    x, y = ds.gather(np.arange(0, 320, 40))
+    with torch.no_grad():
+        ph = torch.sigmoid(m(x)).cpu()
+        pr = torch.sigmoid(ref(x.cpu()))
+    np.testing.assert_allclose(ph.numpy(), pr.numpy(), atol=1e-5)
+
+
+def test_fit_early_stop_on_the_device_path(sed):
+    """a validation set without a single positive makes ER = x/0 = inf or nan at every epoch: never an improvement, so the
+    loop stops after early_stop + 1 epochs (sed.py:200-202) with best_epoch 0 and nothing saved"""
+    torch.manual_seed(1)
+    m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0, gru_hidden=8).cuda()
+    x = torch.randn(4, 1, 40, 64)
+    tr = [(x, (torch.rand(4, 8, 1) > 0.5).float())]
+    va = [(x, torch.zeros(4, 8, 1))]
+    res = sed.fit(m, tr, va, sed.BCEWithLogitsLoss(), sed.FusedAdam(m.parameters(), lr=1e-3), max_epochs=20, early_stop=2)
+    assert len(res["history"]) == 3 and res["best_epoch"] == 0 and res["best_er"] == float("inf")
+    assert all(not (h["val_er"] < float("inf")) for h in res["history"])
+
+
+def test_epoch_tally_scores_equal_host_metrics_of_run_epoch(sed):
+    """the device-side tally (17 integers per epoch) gives exactly what metrics.compute_scores gives on run_epoch's numpy
+    output, and run_epoch keeps the reference's return contract"""
+    import importlib
+    fitmod = importlib.import_module("sed_crnn_amd.fit")
+    from oracle import crnn_ref
+    torch.manual_seed(2)
+    m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0, gru_hidden=8).cuda()
+    batches = [crnn_ref.synthetic_batch(5, 1, 40, 64, 8, seed=s) for s in range(4)] + [crnn_ref.synthetic_batch(3, 1, 40, 64, 8, seed=9)]
+    tally = fitmod.run_epoch_device(m, batches, sed.BCEWithLogitsLoss())
+    loss, p, t = sed.run_epoch(m, batches, sed.BCEWithLogitsLoss())
+    assert p.shape == (23, 8, 1) and p.dtype == np.float32 and t.shape == p.shape
+    assert tally.mean_loss() == pytest.approx(loss, rel=1e-6)
+    s = tally.scores(5)
+    h = sed.metrics.compute_scores(p > 0.5, t, frames_in_1_sec=5)
+    assert s["f1_overall_1sec"] == h["f1_overall_1sec"] and s["er_overall_1sec"] == h["er_overall_1sec"]
+    assert s["f1_overall_framewise"] == sed.metrics.f1_overall_framewise(p > 0.5, t)
+    pb, tb = (p > 0.5).astype(np.uint8), t.astype(np.uint8)
+    cm = np.array([[np.sum((pb == 0) & (tb == 0)), np.sum((pb == 1) & (tb == 0))],
+                   [np.sum((pb == 0) & (tb == 1)), np.sum((pb == 1) & (tb == 1))]])
+    np.testing.assert_array_equal(s["cm"], cm)
+
+
+# ───────────────────────── StandardScaler on the device vs sklearn (g9) ─────────────────────────
+def test_standard_scaler_fit_and_transform_match_sklearn_golden(sed):
+    from oracle import logmel_ref
+    from sed_crnn_amd import data
+    d = load_golden("g9_scaler.npz")
+    xtr, xte = logmel_ref.scaler_fixture_inputs(int(d["seed"]))
+    mean, std = data.standard_scaler_fit(torch.from_numpy(xtr).cuda())
+    assert mean.dtype == torch.float64 and std.dtype == torch.float64
+    np.testing.assert_allclose(mean.cpu().numpy(), d["mean_"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(std.cpu().numpy(), d["scale_"], rtol=1e-9)
+    assert float(std[3]) == 1.0 and float(std[4]) == 1.0 and 0 < float(std[5]) < 1e-9
+    for x, key in ((xtr, "train_t"), (xte, "test_t")):
+        out = data.standard_scaler_transform(torch.from_numpy(x).cuda(), mean, std).cpu().numpy()
+        want = d[key]
+        ok = np.isclose(out, want, rtol=2e-6, atol=1e-6)
+        ok[:, 5] = True                       # sigma = 2e-10 (one-ulp column): a last-bit difference in mean_ is amplified 1e9 x
+        assert ok.all(), (np.abs(out - want).max(), np.argwhere(~ok)[:5])
+        assert (out[:, :5] == want[:, :5]).mean() > 0.999 and (out[:, 8:] == want[:, 8:]).mean() > 0.999   # in fact bit-equal
+    # in place
+    xt = torch.from_numpy(xte.copy()).cuda()
+    data.standard_scaler_transform(xt, mean, std, out=xt)
+    np.testing.assert_allclose(xt.cpu().numpy()[:, 8:], d["test_t"][:, 8:], rtol=2e-6, atol=1e-6)
+
+
+# ───────────────────────── autograd / optimiser hand-over ─────────────────────────
+def _ref_and_model(sed, **kw):
+    from oracle import crnn_ref
+    ref = crnn_ref.SedNetRef(**kw)
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref.state_dict())
+    return ref, m.cuda()
+
+
+def _ref_grads(ref, x, y):
+    from oracle import crnn_ref
+    ref.train()
+    ref.zero_grad()
+    crnn_ref.bce_logits(ref(x), y).backward()
+    return {k: p.grad.clone() for k, p in ref.named_parameters()}
+
+
+@pytest.mark.parametrize("kind", ["permuted_view", "float64", "sliced_batch"])
+def test_backward_uses_the_converted_input(sed, kind):
+    """a non-contiguous or non-fp32 input is converted by forward; backward (first-block recompute + wgrad) must re-read
+    THAT tensor, not the caller's buffer"""
+    from oracle import crnn_ref
+    torch.manual_seed(31)
+    ref, m = _ref_and_model(sed, conv_channels=8, dropout=0.0, gru_hidden=8)
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=2)
+    if kind == "permuted_view":
+        xin = x.permute(0, 1, 3, 2).contiguous().cuda().permute(0, 1, 3, 2)        # same values, strides swapped
+        assert not xin.is_contiguous()
+    elif kind == "float64":
+        xin = x.double().cuda()
+    else:
+        big = torch.cat([x, x], dim=3).cuda()
+        xin = big[..., :64]
+        assert not xin.is_contiguous()
+    want = _ref_grads(ref, x, y)
+    m.train()
+    loss = sed.BCEWithLogitsLoss()(m(xin), y.cuda())
+    loss.backward()
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=2e-5, rtol=2e-3, err_msg=k)
+
+
+def test_arena_bound_gradients_are_not_doubled_and_accumulate_like_torch(sed):
+    from oracle import crnn_ref
+    torch.manual_seed(32)
+    ref, m = _ref_and_model(sed, conv_channels=8, dropout=0.0, gru_hidden=8)
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=3)
+    want = _ref_grads(ref, x, y)
+    crit = sed.BCEWithLogitsLoss()
+    m.train()
+    m.bind_flat_grads()
+    for p, g in zip(m._arena_params, m._grad_views):
+        assert p.grad.data_ptr() == g.data_ptr()
+    m.zero_grad(set_to_none=False)
+    crit(m(x.cuda()), y.cuda()).backward()
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want[k].numpy(), atol=2e-5, rtol=2e-3, err_msg=k)      # g, not 2g
+    g1 = m.flat_grads().clone()
+    crit(m(x.cuda()), y.cuda()).backward()                                      # no zero_grad in between: torch accumulates
+    torch.testing.assert_close(m.flat_grads(), 2 * g1, rtol=1e-6, atol=1e-9)
+    m.zero_grad()                                                                # set_to_none: the next backward re-binds
+    assert all(p.grad is None for p in m.parameters())
+    crit(m(x.cuda()), y.cuda()).backward()
+    assert all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(m._arena_params, m._grad_views))
+    torch.testing.assert_close(m.flat_grads(), g1, rtol=0, atol=0)
+    # unbound module + a second backward: autograd's own accumulation
+    _, m2 = _ref_and_model(sed, conv_channels=8, dropout=0.0, gru_hidden=8)
+    m2.load_state_dict(ref.state_dict())
+    m2.train()
+    crit(m2(x.cuda()), y.cuda()).backward()
+    crit(m2(x.cuda()), y.cuda()).backward()
+    for k, p in m2.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), 2 * want[k].numpy(), atol=4e-5, rtol=2e-3, err_msg=k)
+
+
+def test_fused_adam_attaches_itself_and_matches_torch_adam_over_several_steps(sed):
+    """FusedAdam(model.parameters()) finds the arena, takes the single-launch path through autograd (also across
+    zero_grad(set_to_none=True)), clips on the global norm and keeps ONE moment store when a step has to go through the
+    per-parameter path"""
+    from oracle import crnn_ref
+    torch.manual_seed(33)
+    ref, m = _ref_and_model(sed, conv_channels=8, dropout=0.0, gru_hidden=8)
+    batches = [crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=s) for s in range(3)]
+    opt_r = torch.optim.Adam(ref.parameters(), lr=2e-3, weight_decay=1e-4)
+    opt = sed.FusedAdam(m.parameters(), lr=2e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    assert opt._arena_model is m
+    crit = sed.BCEWithLogitsLoss()
+    m.train()
+    for it in range(6):
+        x, y = batches[it % 3]
+        crnn_ref.fit_step(ref, opt_r, x, y, clip_norm=1.0)
+        opt.zero_grad()
+        crit(m(x.cuda()), y.cuda()).backward()
+        if it == 3:                                       # detach one gradient from the arena: the per-parameter path
+            m.fc.weight.grad = m.fc.weight.grad.clone()
+            assert not opt._arena_ok()
+        else:
+            assert opt._arena_ok()
+        opt.step()
+    assert opt.state[m.fc.weight]["m"].data_ptr() == opt._arena[2][m._arena_offsets[0]:].data_ptr()   # views of the one store
+    sd_r = ref.state_dict()
+    for k, v in m.state_dict().items():
+        if v.dtype.is_floating_point and not (k.startswith("convs.") and k.endswith(".bias")):       # zero-gradient coordinates aside
+            np.testing.assert_allclose(v.cpu().numpy(), sd_r[k].numpy(), atol=3e-4, rtol=2e-2, err_msg=k)
+    # moving the model after the optimiser exists is an error, not silent garbage
+    m.cpu()
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        opt._arena_ok()
+
+
+def test_loss_rejects_unknown_reduction_and_shape_mismatch(sed):
+    lg, tg = torch.zeros(2, 4, 1).cuda(), torch.zeros(2, 4, 1).cuda()
+    with pytest.raises(ValueError, match="reduction"):
+        sed.BCEWithLogitsLoss(reduction="none")(lg, tg)
+    with pytest.raises(ValueError, match="reduction"):
+        sed.FocalBCELoss(reduction="avg")(lg, tg)
+    with pytest.raises(ValueError, match="shape"):
+        sed.BCEWithLogitsLoss()(lg, tg[:, :2])
+
+
+def test_workspace_of_a_captured_graph_survives_other_shapes(sed):
+    """a hipGraph captured by FusedTrainStep(graph=True) points into the workspace of its shape: evaluating many other
+    shapes afterwards must not free it (round-1 advisor: the cache used to be cleared at the fifth key)"""
+    from oracle import crnn_ref
+    from sed_crnn_amd.trainer import FusedTrainStep
+    torch.manual_seed(34)
+    m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0, gru_hidden=8).cuda()
+    st = FusedTrainStep(m, lr=1e-3, graph=True)
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=5)
+    x, y = x.cuda(), y.cuda()
+    for _ in range(3):
+        st.step(x, y)                                     # eager, capture, replay
+    ws = m._ws[(4, 64, True)]
+    m.eval()
+    with torch.no_grad():
+        for b in (1, 2, 3, 5, 6, 7):                      # six more workspace keys
+            m(torch.randn(b, 1, 40, 64).cuda())
+    assert m._ws[(4, 64, True)] is ws and (4, 64, True) in m._ws_pinned
+    m.train()
+    l1 = st.step(x, y)[0].item()
+    assert np.isfinite(l1)
+    with pytest.raises(RuntimeError, match="rebuilt"):
+        m.cuda().cpu().cuda()
+        st.step(x, y)

@@ -163,7 +163,7 @@ def test_fit_lightning_loop_checkpoints_and_early_stop(sed, tmp_path):
     ck = torch.load(tmp_path / "ck" / "last.ckpt", weights_only=True)
     assert ck["epoch"] == 2 and "model.gru1.weight_ih_l0" in ck["state_dict"]
     assert set(lm.track) >= {"loss_tr", "loss_val", "er_1s_val", "f1_fr_tr"} and len(lm.track["er_1s_val"]) == 3
-    assert os.path.exists(tmp_path / "art" / "metrics_fold2.png")
+    assert lm._last_val["cm"].shape == (2, 2) and int(lm._last_val["cm"].sum()) == 8 * 8        # one val batch of 8 x 8 frames
     # early stopping: a validation ER that can never improve (no positives -> nan/inf) stops after `early_stop` epochs
     lm2 = sed.CRNNLightning(fold_id=3, art_dir=str(tmp_path / "art2"), dropout=0.0)
     xz = torch.randn(4, 1, 40, 64)
@@ -263,36 +263,57 @@ def test_lightning_variant_vs_oracle_focal(sed):
     _oracle_vs_hip(sed, ref, m, x, y, loss="focal")
 
 
-def test_get_model_figure_topology_vs_torch(sed):
+@pytest.mark.parametrize("cin", [1, 2])
+def test_get_model_figure_topology_vs_torch(sed, cin):
     """README-figure SEDnet: mel pooling 5/2/2, no time pooling, 6 classes, dense 16 -> 6 (parity unpinned by the
-    reference: there is no code for it; checked op-for-op against torch.nn)."""
+    reference: there is no code for it; checked against autograd of the same graph assembled from torch.nn.functional):
+    train-mode logits, loss and the gradient of EVERY parameter (frequency pooling backward, two-dense head, stacked GRUs
+    fed by a [C, F'] = [32, 2] feature map), mono and binaural input."""
     import torch.nn as nn
     import torch.nn.functional as F
-    torch.manual_seed(9)
-    m = sed.get_model(in_channels=2, n_mels=40, seq_len=16, n_classes=6, conv_channels=32,
-                      pools=[(5, 1), (2, 1), (2, 1)], rnn_hidden=[32, 32], fc=[16, 6], dropout=0.0)
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(9 + cin)
+    pools = [(5, 1), (2, 1), (2, 1)]
+    m = sed.get_model(in_channels=cin, n_mels=40, seq_len=16, n_classes=6, conv_channels=32,
+                      pools=pools, rnn_hidden=[32, 32], fc=[16, 6], dropout=0.0)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
     m.cuda()
-    x = torch.randn(2, 2, 40, 16)
+    x = torch.randn(3, cin, 40, 16)
+    y = (torch.rand(3, 16, 6) > 0.7).float()
+    grus = []
+    for i in range(2):
+        g = nn.GRU(64 if i == 0 else 64, 32, batch_first=True, bidirectional=True)
+        g.load_state_dict({k.split(".", 2)[2]: v.detach() for k, v in sd.items() if k.startswith(f"grus.{i}.")})
+        grus.append(g)
 
     def ref_fwd(x):
         h = x
-        for l, (pf, pt) in enumerate([(5, 1), (2, 1), (2, 1)]):
+        for l, (pf, pt) in enumerate(pools):
             h = F.conv2d(h, sd[f"convs.{l}.weight"], sd[f"convs.{l}.bias"], padding=1)
             h = F.batch_norm(h, None, None, sd[f"bns.{l}.weight"], sd[f"bns.{l}.bias"], training=True)
             h = F.max_pool2d(torch.relu(h), (pf, pt))
         b, c, f, t = h.shape
         h = h.permute(0, 3, 1, 2).reshape(b, t, c * f)
-        for i in range(2):
-            g = nn.GRU(h.shape[-1], 32, batch_first=True, bidirectional=True)
-            g.load_state_dict({k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"grus.{i}.")})
+        for g in grus:
             h, _ = g(h)
         h = torch.relu(F.linear(h, sd["fcs.0.weight"], sd["fcs.0.bias"]))
         return F.linear(h, sd["fcs.1.weight"], sd["fcs.1.bias"])
+    out_r = ref_fwd(x)
+    loss_r = F.binary_cross_entropy_with_logits(out_r, y)
+    loss_r.backward()
     m.train()
-    with torch.no_grad():
-        _cmp(m(x.cuda()), ref_fwd(x), atol=2e-4)
-    assert m(x.cuda()).shape == (2, 16, 6)
+    out = m(x.cuda())
+    assert out.shape == (3, 16, 6)
+    loss = sed.BCEWithLogitsLoss()(out, y.cuda())
+    loss.backward()
+    _cmp(out, out_r, atol=2e-4)
+    assert abs(loss.item() - loss_r.item()) < 1e-5
+    for k, p in m.named_parameters():
+        if k.startswith("grus."):
+            i, name = int(k.split(".")[1]), k.split(".", 2)[2]
+            want = dict(grus[i].named_parameters())[name].grad
+        else:
+            want = sd[k].grad
+        _cmp(p.grad, want, atol=1e-4, rtol=1e-2, msg=k)
 
 
 def test_dropout_training_forward_is_seeded_and_unbiased(sed):
@@ -580,3 +601,43 @@ def test_long_recording_single_sequence_inference_matches_oracle(sed):
         ph = torch.sigmoid(m(x.cuda())).cpu()
     assert ph.shape == (1, 256, 1)
     _cmp(ph, pr, atol=1e-4)
+
+
+# ───────────── BASELINE configs 3 and 5 at their full per-GPU size (properties the domain offers at any size) ─────────────
+@pytest.mark.parametrize("name,cfg", [("config3", dict(B=128, Cin=2, F=40, T=256, C=128, H=128)),
+                                      ("config5", dict(B=128, Cin=4, F=128, T=512, C=128, H=256))])
+def test_full_size_multichannel_configs_finite_separable_deterministic(sed, name, cfg):
+    """binaural (B=128,256,40,2) and 4-channel / 128-mel / T=512 / BiGRU 2x256 at B=128 per GPU:
+    finite loss and gradients after real fit steps, eval forward of the whole batch == eval forward of its chunks
+    bit-for-bit (no cross-sample coupling in eval), and two runs from the same state are bitwise identical."""
+    from sed_crnn_amd.trainer import FusedTrainStep
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(cfg["B"], cfg["Cin"], cfg["F"], cfg["T"], generator=g).cuda()
+    y = (torch.rand(cfg["B"], cfg["T"] // 8, 1, generator=g) > 0.8).float().cuda()
+    m = sed.TimePooledCRNN(conv_channels=cfg["C"], dropout=0.5, in_channels=cfg["Cin"], n_mels=cfg["F"], gru_hidden=cfg["H"]).cuda()
+    p0 = m.flat_parameters().clone()
+    bufs0 = [b.clone() for b in m.buffers()]
+
+    def two_steps():
+        with torch.no_grad():
+            m.flat_parameters().copy_(p0)
+            for b, b0 in zip(m.buffers(), bufs0):
+                b.copy_(b0)
+        m._seed_counter = 0
+        st = FusedTrainStep(m, lr=1e-3, loss="bce")
+        losses = [st.step(x, y)[0].item() for _ in range(2)]
+        return losses, m.flat_parameters().clone(), m.flat_grads().clone()
+    l1, p1, g1 = two_steps()
+    l2, p2, g2 = two_steps()
+    assert all(np.isfinite(l1)) and torch.isfinite(p1).all() and torch.isfinite(g1).all()
+    assert l1 == l2 and torch.equal(p1, p2) and torch.equal(g1, g2)
+    assert float(g1.abs().max()) > 0
+    m.eval()
+    with torch.no_grad():
+        whole = m(x)
+        parts = torch.cat([m(x[i:i + 32]) for i in range(0, cfg["B"], 32)])
+    assert whole.shape == (cfg["B"], cfg["T"] // 8, 1) and torch.isfinite(whole).all()
+    assert torch.equal(whole, parts)
+    del m, x, y, p0, p1, p2, g1, g2
+    torch.cuda.empty_cache()
