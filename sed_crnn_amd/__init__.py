@@ -7,7 +7,7 @@ FocalBCELoss / CRNNLightning (crnn_lightning.py), metrics.compute_scores (metric
 """
 from . import metrics  # noqa: F401
 from ._lib import LIB_PATH, SedHipError, lib  # noqa: F401
-from .fit import fit, run_epoch  # noqa: F401
+from .fit import EpochTally, fit, fit_folds, run_epoch, run_epoch_device  # noqa: F401
 from .lightning import CRNNLightning, fit_lightning  # noqa: F401
 from .losses import BCEWithLogitsLoss, FocalBCELoss  # noqa: F401
 from .model import (HipCRNN, LightningTimePooledCRNN, SEDNet, TimePooledCRNN,  # noqa: F401
