@@ -213,12 +213,21 @@ int sed_adam_step(float* p, const float* g, float* m, float* v, long n, float lr
 int sed_step_advance(uint64_t* step_state, void* stream);
 
 /* ───────────── log-mel front end (feature.py:55-59 via librosa.stft / filters.mel) ─────────────
- * pcm [n_samples] mono f32 -> out [n_frames][n_mels] = log(mel @ |STFT|^2), n_frames = 1 + n_samples/hop.
- * window [n_fft], melfb [n_mels][n_fft/2+1] and twiddle [n_fft/2][2] (cos,-sin of 2*pi*k/n_fft) are
- * supplied by the host (computed in double).  pad_mode 0 = zeros ("constant"), 1 = reflect.
- * mu/inv_sigma (may be NULL) fuse feature.py:127-129's StandardScaler: (x-mu)*inv_sigma. n_fft must be 2048. */
-int sed_logmel(const float* pcm, long n_samples, const float* window, const float* twiddle,
-               const float* melfb, const float* mu, const float* inv_sigma, float* out,
+ * pcm [n_samples] mono f32 -> out [n_frames][n_mels] = log(mel @ |STFT|^2), n_frames = 1 + n_samples/hop; frames are
+ * centred (librosa center=True): frame f covers samples [f*hop - n_fft/2, f*hop + n_fft/2), padded per pad_mode
+ * (0 = zeros, librosa >= 0.10 "constant"; 1 = numpy "reflect", older librosa).  n_fft must be 2048.
+ * The constant tables travel as ONE blob that the kernel keeps in LDS.  It is built on the HOST (no GPU call) from
+ * host arrays: window [n_fft] and melfb [n_mels][n_fft/2+1] (both computed in double by the caller, librosa's Hann /
+ * Slaney bank in sed_crnn_amd/feature.py); the builder adds the FFT twiddles and turns the filterbank into its sparse
+ * band-major form (any bank whose non-zeros fit the plan: <= 8192 of them, n_mels <= 128).
+ *   sed_logmel_tables_bytes  -> size of the blob for this bank (0 = cannot be planned);
+ *   sed_logmel_build_tables  -> fills tables_host; the caller copies it to the device once.
+ * sed_logmel: mu/inv_sigma (device, may both be NULL) fuse feature.py:127-129's StandardScaler: (x-mu)*inv_sigma. */
+size_t sed_logmel_tables_bytes(const float* melfb_host, int n_fft, int n_mels);
+int sed_logmel_build_tables(const float* window_host, const float* melfb_host, int n_fft, int n_mels,
+                            void* tables_host, size_t tables_bytes);
+int sed_logmel(const float* pcm, long n_samples, const void* tables, size_t tables_bytes,
+               const float* mu, const float* inv_sigma, float* out,
                int n_fft, int hop, int n_mels, int pad_mode, void* stream);
 
 /* ───────────── GPU-resident minibatch assembly (sed.py:64-79; decorte_datamodule.py:39-49,77-111; utils.py:15-41) ─────────────
@@ -347,6 +356,7 @@ enum sed_kernel_tag {
     SED_K_GRU_FWD,             /* units: FLOPs */
     SED_K_GRU_BWD,             /* units: FLOPs */
     SED_K_ADAM,                /* units: bytes */
+    SED_K_LOGMEL,              /* units: bytes (hop*4 read + n_mels*4 written per frame) */
     SED_K_COUNT
 };
 int sed_prof_enable(unsigned tag_mask);

@@ -87,7 +87,9 @@ SIGNATURES = {
     "sed_grad_norm_clip_coef": (_i, [_fp, _l, _f, _fp, _fp, _stream]),
     "sed_adam_step": (_i, [_fp, _fp, _fp, _fp, _l, _f, _f, _f, _f, _f, _i, _fp, _fp, _stream]),
     "sed_step_advance": (_i, [_fp, _stream]),
-    "sed_logmel": (_i, [_fp, _l, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
+    "sed_logmel_tables_bytes": (_sz, [_fp, _i, _i]),
+    "sed_logmel_build_tables": (_i, [_fp, _fp, _i, _i, _fp, _sz]),
+    "sed_logmel": (_i, [_fp, _l, _fp, _sz, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
     "sed_window_batch": (_i, [_fp, _fp, _l, _i, _i, _i, _fp, _fp, _fp, _i, _i, _i, _fp, _fp, _i, _i, _i, _stream]),
     "sed_pack_sequences": (_i, [_fp, _l, _i, _i, _i, _i, _fp, _stream]),
     "sed_col_mean_std_workspace_bytes": (_sz, [_i]),

@@ -14,6 +14,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libsedcrnn.so")
 SOURCES = ["api.cpp", "conv.hip", "conv1.hip", "bnpool.hip", "gemm.hip", "gru.hip", "misc.hip", "logmel.hip", "data.hip", "net.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file extras.  logmel: the SLP vectoriser packs the FFT's scalar adds into v_pk_add_f32 and pays for it with ~600
+# v_mov per frame pair to build the register pairs (packed f32 is no faster than scalar on gfx950)
+EXTRA_FLAGS = {"logmel.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -41,7 +44,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
             jobs.append(cmd)
 
     def run(cmd):

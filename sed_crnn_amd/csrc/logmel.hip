@@ -1,89 +1,458 @@
-// logmel.hip — log-mel front end: framing + Hann + 2048-point FFT -> |.|^2 -> 40x1025 mel matmul -> log.
+// logmel.hip — log-mel front end: framing + window + 2048-point real FFT -> |.|^2 -> mel filterbank -> log.
 //
 // Replaces librosa.stft / librosa.filters.mel / np.log as called by _mbe at reference feature.py:55-59
-// (and, optionally fused, the StandardScaler of feature.py:127-129).  One workgroup per frame: the frame
-// (8 KB of PCM, read twice across frames because of the 50 % hop) is staged in LDS, transformed in place
-// with a radix-2 DIT FFT (11 stages, 4 butterflies per thread per stage), and only 40 floats per frame
-// go back to HBM, so the kernel is bound by the PCM read.
+// (and, optionally fused, the StandardScaler of feature.py:127-129).
+//
+// Shape of the kernel (gfx950):
+//   * a 2048-sample REAL frame is one 1024-point COMPLEX transform of z[n] = x[2n] + i x[2n+1] plus a pairing pass
+//     (X[k] from Z[k] and conj Z[1024-k]) — half the butterflies of the complex transform of the frame;
+//   * 1024 = 32 x 32: every lane does a 32-point FFT entirely in registers (compile-time twiddles), the 32 lanes of a
+//     HALF wave exchange once through LDS (32x33-float transposes, conflict-free) and do a second 32-point FFT, so a wave
+//     transforms TWO frames at a time and needs no workgroup barrier: waves are independent and loop over frame pairs;
+//   * window, inter-pass twiddles W_1024^{rq}, pairing twiddles W_2048^k and the mel filterbank live in LDS, loaded once
+//     per (persistent) workgroup; the filterbank is applied in its sparse form (a Slaney bank has 2 050 non-zeros of
+//     41 000): band-major entry list, 1/32 of it per lane, partial sums combined in a fixed order (deterministic);
+//   * HBM traffic is the PCM once (the 50 % overlap of neighbouring frames is re-read by the neighbouring half wave at
+//     the same time and comes from L2) + 40 floats per frame.
+// Algorithmic bytes per frame: hop*4 read + n_mels*4 written (4 256 B at hop 1024 / 40 mel).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
 #include "common.h"
 
 #define LM_NFFT 2048
-#define LM_LOG2 11
+#define LM_N 1024                     // complex points
+#define LM_TSTRIDE 33                 // floats per row of the 32x32 transpose (conflict-free both ways)
+#define LM_SCR (32 * LM_TSTRIDE)      // 1056 floats >= 1025 power bins
+#define LM_MAX_MELS 128
+#define LM_PART (32 + LM_MAX_MELS)    // partial-sum slots per frame (plan 1: 2 per stored pair + the zero slot)
+#define LM_TRI_BINS 33
+#define LM_FRAME_SCR (LM_SCR + LM_PART)
+#define LM_HDR 8                      // table header words
 
-__device__ __forceinline__ int bitrev11(int i) { return (int)(__brev((unsigned)i) >> (32 - LM_LOG2)); }
+// table blob (32-bit words):  [0] magic  [1] n_mels  [2] iters  [3] n_slots  [4] total words  [5] plan (0 list, 1 two-band)  [6..7] 0
+//   win  [2048]            window, natural order
+//   tw   [32][32] float2   tw[q][r] = exp(-2 pi i r q / 1024)
+//   pw   [513]   float2    exp(-2 pi i k / 2048), k = 0..512 (+ 1 pad float2)
+//  plan 0 (any sparse bank): band-major list of the non-zeros, 1/32 of it per lane
+//   ent  [iters][32] {float weight*0.25, u32 meta}    meta = k | emit << 11 | slot << 12
+//   band [n_mels] u32      first_slot | count << 16
+//  plan 1 (every bin feeds at most two ADJACENT bands — triangular banks such as librosa's): lane r owns the 33
+//  consecutive bins 33r .. 33r+32, keeps one accumulator for the lower and one for the upper band of the current bin and
+//  stores the pair whenever the band pair changes (iters = 33)
+//   ent  [33][32] {float w_lower*0.25, float w_upper*0.25, u32 pair_slot (float index into part, even) or ~0, 0}
+//   band [n_mels][8] u16   float indices into part of the partial sums of the band (unused = the always-zero slot)
+#define LM_MAGIC 0x4C4D3332u
+#define LM_OFF_WIN LM_HDR
+#define LM_OFF_TW (LM_OFF_WIN + 2048)
+#define LM_OFF_PW (LM_OFF_TW + 2048)
+#define LM_OFF_ENT (LM_OFF_PW + 1028)
 
-__global__ __launch_bounds__(256) void logmel_k(const float* __restrict__ pcm, long n_samples,
-                                                const float* __restrict__ window, const float* __restrict__ tw,
-                                                const float* __restrict__ melfb, const float* __restrict__ mu,
-                                                const float* __restrict__ inv_sigma, float* __restrict__ out,
-                                                int hop, int n_mels, int pad_mode) {
-    __shared__ float re[LM_NFFT], im[LM_NFFT];
-    __shared__ float pw[LM_NFFT / 2 + 1];
-    const int tid = threadIdx.x;
-    const long frame = blockIdx.x;
-    const long start = frame * hop - LM_NFFT / 2;
-    for (int i = tid; i < LM_NFFT; i += 256) {
-        long n = start + i;
-        float v = 0.f;
-        if (n >= 0 && n < n_samples) v = pcm[n];
-        else if (pad_mode == 1 && n_samples > 1) {                    // numpy 'reflect' (no edge repeat)
-            long period = 2 * (n_samples - 1);
-            long r = n % period;
-            if (r < 0) r += period;
-            if (r >= n_samples) r = period - r;
-            v = pcm[r];
-        }
-        int j = bitrev11(i);
-        re[j] = v * window[i];
-        im[j] = 0.f;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int s = 0; s < LM_LOG2; ++s) {
-        const int m = 1 << s;
-        const int tstride = (LM_NFFT / 2) >> s;
+namespace {
+
+__device__ __forceinline__ constexpr int brev5(int k) {
+    return ((k & 1) << 4) | ((k & 2) << 2) | (k & 4) | ((k & 8) >> 2) | ((k & 16) >> 4);
+}
+
+// 32-point DIF FFT in registers, forward sign; result X[k] = a[brev5(k)].  All indices are compile-time constants.
+__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+    constexpr float C32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                               0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                               0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                               -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                               -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                               0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                               0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                               0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                               0.38268343236508977173f, 0.19509032201612826785f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int j = tid + u * 256;
-            int pos = j & (m - 1);
-            int i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + m;
-            float wr = tw[2 * pos * tstride], wi = tw[2 * pos * tstride + 1];
-            float xr = re[i1], xi = im[i1];
-            float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-            float ar = re[i0], ai = im[i0];
-            re[i0] = ar + tr; im[i0] = ai + ti;
-            re[i1] = ar - tr; im[i1] = ai - ti;
-        }
-        __syncthreads();
-    }
-    for (int k = tid; k <= LM_NFFT / 2; k += 256) pw[k] = re[k] * re[k] + im[k] * im[k];
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    const int nb = LM_NFFT / 2 + 1;
-    for (int mI = wave; mI < n_mels; mI += 4) {
-        const float* fb = melfb + (size_t)mI * nb;
-        float a = 0.f;
-        for (int k = lane; k < nb; k += 64) a += fb[k] * pw[k];
-        a = wave_sum(a);
-        if (lane == 0) {
-            float v = logf(a);
-            if (mu) v = (v - mu[mI]) * inv_sigma[mI];
-            out[frame * n_mels + mI] = v;
+    for (int h = 16; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < 32; blk += 2 * h) {
+#pragma unroll
+            for (int j = 0; j < h; ++j) {
+                const int i0 = blk + j, i1 = i0 + h;
+                const int m = j * (16 / h);                 // twiddle W_32^m = C32[m] - i S32[m]
+                const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
+                re[i0] = ur + vr; im[i0] = ui + vi;
+                const float dr = ur - vr, di = ui - vi;
+                if (m == 0) { re[i1] = dr; im[i1] = di; }
+                else if (m == 8) { re[i1] = di; im[i1] = -dr; }
+                else { re[i1] = dr * C32[m] + di * S32[m]; im[i1] = di * C32[m] - dr * S32[m]; }
+            }
         }
     }
 }
 
-extern "C" int sed_logmel(const float* pcm, long n_samples, const float* window, const float* twiddle,
-                          const float* melfb, const float* mu, const float* inv_sigma, float* out, int n_fft,
-                          int hop, int n_mels, int pad_mode, void* stream) {
-    SED_REQUIRE(pcm && window && twiddle && melfb && out, "logmel: null pointer");
-    SED_REQUIRE(n_fft == LM_NFFT, "logmel: n_fft must be %d (got %d)", LM_NFFT, n_fft);
-    SED_REQUIRE(n_samples > 0 && hop > 0 && n_mels > 0, "logmel: bad sizes");
-    SED_REQUIRE((mu == nullptr) == (inv_sigma == nullptr), "logmel: mu and inv_sigma go together");
-    SED_REQUIRE(pad_mode == 0 || pad_mode == 1, "logmel: pad_mode must be 0 (constant) or 1 (reflect)");
-    long frames = 1 + n_samples / hop;
-    logmel_k<<<(unsigned)frames, 256, 0, as_stream(stream)>>>(pcm, n_samples, window, twiddle, melfb, mu, inv_sigma, out,
-                                                              hop, n_mels, pad_mode);
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS operations of ONE wave are executed in order by the hardware; this only stops the compiler from moving
+    // them across the point where another lane of the same wave takes over the data
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float pcm_at(const float* __restrict__ pcm, long n, long n_samples, int pad_mode) {
+    if (n >= 0 && n < n_samples) return pcm[n];
+    if (pad_mode == 1 && n_samples > 1) {                    // numpy 'reflect' (no edge repeat)
+        const long period = 2 * (n_samples - 1);
+        long r = n % period;
+        if (r < 0) r += period;
+        if (r >= n_samples) r = period - r;
+        return pcm[r];
+    }
+    return 0.f;
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict__ pcm, long n_samples,
+                                                         const uint32_t* __restrict__ tables, int table_words,
+                                                         const float* __restrict__ mu, const float* __restrict__ inv_sigma,
+                                                         float* __restrict__ out, long n_frames, int hop, int pad_mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    {   // tables: global -> LDS, once per workgroup (table_words is a multiple of 4)
+        const f32x4* src = reinterpret_cast<const f32x4*>(tables);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int i = tid; i < table_words / 4; i += WPB * 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(lds);
+    const int n_mels = (int)hdr[1], iters = (int)hdr[2];
+    const bool two_band = hdr[5] != 0;                       // which mel plan the blob carries (wave-uniform)
+    const float2* s_win = reinterpret_cast<const float2*>(lds + LM_OFF_WIN);
+    const float2* s_tw = reinterpret_cast<const float2*>(lds + LM_OFF_TW);
+    const float2* s_pw = reinterpret_cast<const float2*>(lds + LM_OFF_PW);
+    const float2* s_ent = reinterpret_cast<const float2*>(lds + LM_OFF_ENT);
+    const uint32_t* s_band = reinterpret_cast<const uint32_t*>(lds + LM_OFF_ENT + (size_t)iters * 64);
+
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, r = lane & 31;
+    float* scr = lds + table_words + (wave * 2 + half) * LM_FRAME_SCR;      // this half wave's transpose / power buffer
+    float* part = scr + LM_SCR;
+    const int partner = (lane & 32) | ((32 - r) & 31);
+    const bool even_hop = (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0;
+    const long n_pairs = (n_frames + 1) >> 1;
+
+    for (long pair = (long)blockIdx.x * WPB + wave; pair < n_pairs; pair += (long)gridDim.x * WPB) {
+        long frame = pair * 2 + half;
+        const bool live = frame < n_frames;
+        if (!live) frame = n_frames - 1;                     // odd tail: the upper half recomputes the last frame, stores nothing
+        const long start = frame * hop - LM_NFFT / 2;
+        float re[32], im[32];
+        // ── load z[32 n1 + r] = (x[64 n1 + 2r], x[64 n1 + 2r + 1]) * window ──
+        const long first = pair * 2 * hop - LM_NFFT / 2, last = first + hop + LM_NFFT;     // span of both frames (wave-uniform)
+        if (even_hop && first >= 0 && last <= n_samples) {
+            const float2* src = reinterpret_cast<const float2*>(pcm + start) + r;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) { const float2 v = src[32 * n1]; re[n1] = v.x; im[n1] = v.y; }
+        } else {                                             // edge frames / odd hop: guarded loads, staged through LDS so that
+            wave_lds_fence();                                //  this cold path costs no registers (dynamic index, not unrolled)
+#pragma unroll 1
+            for (int n1 = 0; n1 < 32; ++n1) scr[n1 * 32 + r] = pcm_at(pcm, start + 64 * n1 + 2 * r, n_samples, pad_mode);
+            wave_lds_fence();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) re[n1] = scr[n1 * 32 + r];
+            wave_lds_fence();
+#pragma unroll 1
+            for (int n1 = 0; n1 < 32; ++n1) scr[n1 * 32 + r] = pcm_at(pcm, start + 64 * n1 + 2 * r + 1, n_samples, pad_mode);
+            wave_lds_fence();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) im[n1] = scr[n1 * 32 + r];
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) { const float2 w = s_win[32 * n1 + r]; re[n1] *= w.x; im[n1] *= w.y; }
+
+        // ── pass 1: FFT over n1, twiddle W_1024^{r k1} ──
+        fft32(re, im);
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) {
+            const float2 w = s_tw[k1 * 32 + r];
+            const int b = brev5(k1);
+            const float xr = re[b], xi = im[b];
+            re[b] = xr * w.x - xi * w.y;
+            im[b] = xr * w.y + xi * w.x;
+        }
+        // ── transpose through LDS (real parts, then imaginary parts, same 32x33 buffer): lane r holds A[r][k1], lane c
+        //    needs A[n2][c] ──
+        wave_lds_fence();                                    // the previous frame's mel pass has finished reading scr
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) scr[r * LM_TSTRIDE + k1] = re[brev5(k1)];
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) re[n2] = scr[n2 * LM_TSTRIDE + r];
+        wave_lds_fence();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) scr[r * LM_TSTRIDE + k1] = im[brev5(k1)];
+        wave_lds_fence();
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) im[n2] = scr[n2 * LM_TSTRIDE + r];
+        wave_lds_fence();
+        // ── pass 2: FFT over n2 -> Z[r + 32 k2] = (re, im)[brev5(k2)] ──
+        fft32(re, im);
+        // ── pairing: 2 X[k] = (Z[k] + conj Z[N-k]) - i W_2048^k (Z[k] - conj Z[N-k]); lane r owns k = r + 32 k2, k2 < 16, and
+        //    its mirror N-k, whose Z lives in lane (32 - r) % 32, register 31 - k2 (lane 0: its own register 32 - k2) ──
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const int b = brev5(k2), bp = brev5(31 - k2), b0 = brev5((32 - k2) & 31);
+            const float zr = re[b], zi = im[b];
+            float pr = __shfl(re[bp], partner, 64), pi = __shfl(im[bp], partner, 64);
+            if (r == 0) { pr = re[b0]; pi = im[b0]; }
+            const int k = r + 32 * k2;
+            const float2 w = s_pw[k];
+            const float er = zr + pr, ei = zi - pi, qr = zi + pi, qi = pr - zr;
+            const float tr = w.x * qr - w.y * qi, ti = w.x * qi + w.y * qr;
+            const float ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
+            scr[k] = ar * ar + ai * ai;                      // 4 |X[k]|^2   (the 1/4 is folded into the mel weights)
+            scr[LM_N - k] = br * br + bi * bi;               // 4 |X[N-k]|^2
+        }
+        if (r == 0) { const float zr = re[brev5(16)], zi = im[brev5(16)]; scr[512] = 4.f * (zr * zr + zi * zi); }
+        wave_lds_fence();
+        if (two_band) {
+            // ── two-band plan: bins 33r .. 33r+32 (bins past 1024 carry zero weights; their slots are cleared so that a
+            //    stale non-finite value cannot turn 0*x into NaN) ──
+            if (r > 0) scr[LM_N + r] = 0.f;
+            if (r == 0) part[LM_PART - 1] = 0.f;             // the always-zero slot the band lists pad with
+            wave_lds_fence();
+            const f32x4* ent = reinterpret_cast<const f32x4*>(s_ent) + r;
+            const float* pb = scr + LM_TRI_BINS * r;
+            float lo = 0.f, hi = 0.f;
+#pragma unroll
+            for (int i = 0; i < LM_TRI_BINS; ++i) {
+                const f32x4 e = ent[i * 32];
+                const float pv = pb[i];
+                lo = fmaf(e[0], pv, lo);
+                hi = fmaf(e[1], pv, hi);
+                const uint32_t slot = __float_as_uint(e[2]);
+                if ((int32_t)slot >= 0) {
+                    *reinterpret_cast<float2*>(part + slot) = make_float2(lo, hi);
+                    lo = 0.f; hi = 0.f;
+                }
+            }
+            wave_lds_fence();
+            const uint4* blist = reinterpret_cast<const uint4*>(lds + LM_OFF_ENT + LM_TRI_BINS * 32 * 4);
+            for (int m = r; m < n_mels; m += 32) {
+                const uint4 l = blist[m];
+                float v = part[l.x & 0xffffu];                // fixed summation order: deterministic
+                v += part[l.x >> 16];
+                v += part[l.y & 0xffffu];
+                v += part[l.y >> 16];
+                v += part[l.z & 0xffffu];
+                v += part[l.z >> 16];
+                v += part[l.w & 0xffffu];
+                v += part[l.w >> 16];
+                v = logf(v);
+                if (mu) v = (v - mu[m]) * inv_sigma[m];
+                if (live) out[frame * n_mels + m] = v;
+            }
+        } else {
+            // ── list plan: lane r walks entries [r*iters, (r+1)*iters) of the band-major list ──
+            float acc = 0.f;
+            for (int i0 = 0; i0 < iters; i0 += 8) {          // iters is a multiple of 8; 8 independent LDS reads in flight
+                float2 e[8];
+                float pv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = s_ent[(i0 + u) * 32 + r];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) pv[u] = scr[__float_as_uint(e[u].y) & 0x7ffu];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t meta = __float_as_uint(e[u].y);
+                    acc = fmaf(e[u].x, pv[u], acc);
+                    if (meta & 0x800u) { part[meta >> 12] = acc; acc = 0.f; }
+                }
+            }
+            wave_lds_fence();
+            for (int m = r; m < n_mels; m += 32) {
+                const uint32_t bt = s_band[m];
+                const int f0 = (int)(bt & 0xffffu), cnt = (int)(bt >> 16);
+                float v = 0.f;
+                for (int j = 0; j < cnt; ++j) v += part[f0 + j];
+                v = logf(v);
+                if (mu) v = (v - mu[m]) * inv_sigma[m];
+                if (live) out[frame * n_mels + m] = v;
+            }
+        }
+    }
+}
+
+struct LmPlan { int n_mels, iters, n_slots, words, tri; std::vector<uint32_t> ent, band; };
+
+// plan 0: band-major non-zero list of a dense [n_mels][1025] bank, 1/32 per lane; returns 0 when it cannot be planned
+int plan_list(const float* fb, int n_mels, LmPlan* p) {
+    const int nb = LM_NFFT / 2 + 1;
+    std::vector<int> ek, eb;
+    std::vector<float> ew;
+    for (int m = 0; m < n_mels; ++m) {
+        bool any = false;
+        for (int k = 0; k < nb; ++k)
+            if (fb[(size_t)m * nb + k] != 0.f) { ek.push_back(k); eb.push_back(m); ew.push_back(fb[(size_t)m * nb + k]); any = true; }
+        if (!any) { ek.push_back(0); eb.push_back(m); ew.push_back(0.f); }     // an empty band still owns a slot (log 0 = -inf)
+    }
+    const int nnz = (int)ek.size();
+    const int iters = ((nnz + 31) / 32 + 7) & ~7;             // per-lane entries, padded to the kernel's unroll of 8
+    if (iters > 256) return 0;
+    p->ent.assign((size_t)iters * 64, 0u);
+    p->band.assign(n_mels, 0u);
+    int slot = 0;
+    std::vector<int> first(n_mels, -1), cnt(n_mels, 0);
+    for (int lane = 0; lane < 32; ++lane) {
+        for (int i = 0; i < iters; ++i) {
+            const int e = lane * iters + i;
+            if (e >= nnz) break;
+            const bool emit = (i == iters - 1) || (e == nnz - 1) || (eb[e + 1] != eb[e]);
+            const size_t at = ((size_t)i * 32 + lane) * 2;
+            const float w = 0.25f * ew[e];
+            memcpy(&p->ent[at], &w, 4);
+            p->ent[at + 1] = (uint32_t)ek[e] | (emit ? 0x800u : 0u) | ((uint32_t)slot << 12);
+            if (emit) {
+                const int m = eb[e];
+                if (first[m] < 0) first[m] = slot;
+                ++cnt[m];
+                ++slot;
+            }
+        }
+    }
+    if (slot > LM_PART) return 0;
+    for (int m = 0; m < n_mels; ++m) p->band[m] = (uint32_t)first[m] | ((uint32_t)cnt[m] << 16);
+    p->n_mels = n_mels; p->iters = iters; p->n_slots = slot; p->tri = 0;
+    p->words = (LM_OFF_ENT + iters * 64 + n_mels + 3) & ~3;
+    return 1;
+}
+
+// plan 1: every bin feeds at most two adjacent bands; returns 0 when the bank is not of that shape
+int plan_two_band(const float* fb, int n_mels, LmPlan* p) {
+    const int nb = LM_NFFT / 2 + 1;
+    std::vector<int> lower(nb, 0);                            // band of the "lower" accumulator at bin k (upper = lower + 1)
+    int prev = 0;
+    for (int k = 0; k < nb; ++k) {
+        int b0 = -1, b1 = -1, n = 0;
+        for (int m = 0; m < n_mels; ++m)
+            if (fb[(size_t)m * nb + k] != 0.f) { if (n == 0) b0 = m; else b1 = m; ++n; }
+        if (n > 2 || (n == 2 && b1 != b0 + 1)) return 0;
+        if (n == 2) prev = b0;
+        else if (n == 1 && b0 != prev && b0 != prev + 1) prev = b0;
+        lower[k] = prev;
+    }
+    p->ent.assign((size_t)LM_TRI_BINS * 32 * 4, 0u);
+    std::vector<std::vector<int>> slots(n_mels);
+    int pair = 0;
+    for (int lane = 0; lane < 32; ++lane) {
+        bool used_lo = false, used_hi = false;
+        for (int i = 0; i < LM_TRI_BINS; ++i) {
+            const int k = LM_TRI_BINS * lane + i;
+            const size_t at = ((size_t)i * 32 + lane) * 4;
+            p->ent[at + 2] = 0xffffffffu;
+            if (k >= nb) continue;
+            const int L = lower[k];
+            const float wl = 0.25f * fb[(size_t)L * nb + k];
+            const float wh = (L + 1 < n_mels) ? 0.25f * fb[(size_t)(L + 1) * nb + k] : 0.f;
+            memcpy(&p->ent[at], &wl, 4);
+            memcpy(&p->ent[at + 1], &wh, 4);
+            used_lo |= wl != 0.f; used_hi |= wh != 0.f;
+            const bool last = (i == LM_TRI_BINS - 1) || (k == nb - 1) || (lower[k + 1] != L);
+            if (!last) continue;
+            if (used_lo || used_hi) {
+                p->ent[at + 2] = (uint32_t)(2 * pair);
+                if (used_lo) slots[L].push_back(2 * pair);
+                if (used_hi) slots[L + 1].push_back(2 * pair + 1);
+                ++pair;
+            } else {
+                p->ent[at + 2] = 0xfffffffeu;                 // nothing accumulated: no store (accumulators are zero anyway)
+            }
+            used_lo = used_hi = false;
+        }
+    }
+    if (2 * pair > LM_PART - 1) return 0;
+    p->band.assign((size_t)n_mels * 4, 0u);
+    const uint32_t zero_slot = LM_PART - 1;
+    for (int m = 0; m < n_mels; ++m) {
+        if (slots[m].size() > 8) return 0;
+        uint32_t l[8];
+        for (int j = 0; j < 8; ++j) l[j] = j < (int)slots[m].size() ? (uint32_t)slots[m][j] : zero_slot;
+        for (int j = 0; j < 4; ++j) p->band[(size_t)m * 4 + j] = l[2 * j] | (l[2 * j + 1] << 16);
+    }
+    p->n_mels = n_mels; p->iters = LM_TRI_BINS; p->n_slots = 2 * pair; p->tri = 1;
+    p->words = (LM_OFF_ENT + LM_TRI_BINS * 32 * 4 + n_mels * 4 + 3) & ~3;
+    return 1;
+}
+
+int plan_mel(const float* fb, int n_mels, LmPlan* p) {
+    if (!getenv("SED_LOGMEL_LIST_PLAN") && plan_two_band(fb, n_mels, p)) return 1;
+    return plan_list(fb, n_mels, p);
+}
+
+}  // namespace
+
+extern "C" size_t sed_logmel_tables_bytes(const float* melfb_host, int n_fft, int n_mels) {
+    if (!melfb_host || n_fft != LM_NFFT || n_mels <= 0 || n_mels > LM_MAX_MELS) return 0;
+    LmPlan p;
+    if (!plan_mel(melfb_host, n_mels, &p)) return 0;
+    return (size_t)p.words * 4;
+}
+
+extern "C" int sed_logmel_build_tables(const float* window_host, const float* melfb_host, int n_fft, int n_mels,
+                                       void* tables_host, size_t tables_bytes) {
+    SED_REQUIRE(window_host && melfb_host && tables_host, "logmel_build_tables: null pointer");
+    SED_REQUIRE(n_fft == LM_NFFT, "logmel_build_tables: n_fft must be %d (got %d)", LM_NFFT, n_fft);
+    SED_REQUIRE(n_mels > 0 && n_mels <= LM_MAX_MELS, "logmel_build_tables: n_mels must be in [1,%d]", LM_MAX_MELS);
+    LmPlan p;
+    SED_REQUIRE(plan_mel(melfb_host, n_mels, &p),
+                "logmel_build_tables: filterbank has too many non-zeros for the LDS-resident sparse plan");
+    SED_REQUIRE(tables_bytes >= (size_t)p.words * 4, "logmel_build_tables: buffer too small (%zu < %zu)", tables_bytes, (size_t)p.words * 4);
+    uint32_t* t = (uint32_t*)tables_host;
+    memset(t, 0, (size_t)p.words * 4);
+    t[0] = LM_MAGIC; t[1] = (uint32_t)n_mels; t[2] = (uint32_t)p.iters; t[3] = (uint32_t)p.n_slots; t[4] = (uint32_t)p.words;
+    t[5] = (uint32_t)p.tri;
+    float* f = (float*)tables_host;
+    memcpy(f + LM_OFF_WIN, window_host, LM_NFFT * sizeof(float));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int q = 0; q < 32; ++q)
+        for (int r = 0; r < 32; ++r) {
+            const double a = two_pi * (double)((r * q) % LM_N) / (double)LM_N;
+            f[LM_OFF_TW + (q * 32 + r) * 2] = (float)cos(a);
+            f[LM_OFF_TW + (q * 32 + r) * 2 + 1] = (float)(-sin(a));
+        }
+    for (int k = 0; k <= 512; ++k) {
+        const double a = two_pi * (double)k / (double)LM_NFFT;
+        f[LM_OFF_PW + 2 * k] = (float)cos(a);
+        f[LM_OFF_PW + 2 * k + 1] = (float)(-sin(a));
+    }
+    memcpy(t + LM_OFF_ENT, p.ent.data(), p.ent.size() * 4);
+    memcpy(t + LM_OFF_ENT + p.ent.size(), p.band.data(), p.band.size() * 4);
+    return 0;
+}
+
+template <int WPB>
+static int launch_logmel(const float* pcm, long n_samples, const void* tables, int words, const float* mu, const float* inv_sigma,
+                         float* out, long frames, int hop, int n_mels, int pad_mode, hipStream_t s) {
+    const size_t lds = (size_t)words * 4 + (size_t)WPB * 2 * LM_FRAME_SCR * sizeof(float);
+    SED_REQUIRE(lds <= 160 * 1024, "logmel: tables + scratch (%zu B) exceed the 160 KiB LDS", lds);
+    hipError_t e = hipFuncSetAttribute((const void*)logmel_fft_k<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { sed_set_error("logmel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    const long pairs = (frames + 1) / 2;
+    long blocks = (pairs + WPB - 1) / WPB;
+    const long resident = 256;                               // one persistent workgroup per CU: the tables are loaded once each
+    if (blocks > resident) blocks = resident;
+    SedProfScope prof(SED_K_LOGMEL, s, (double)frames * ((double)hop + n_mels) * 4.0);
+    logmel_fft_k<WPB><<<(unsigned)blocks, WPB * 64, lds, s>>>(pcm, n_samples, (const uint32_t*)tables, words, mu, inv_sigma,
+                                                              out, frames, hop, pad_mode);
     SED_LAUNCH_CHECK("logmel");
     return 0;
+}
+
+extern "C" int sed_logmel(const float* pcm, long n_samples, const void* tables, size_t tables_bytes, const float* mu,
+                          const float* inv_sigma, float* out, int n_fft, int hop, int n_mels, int pad_mode, void* stream) {
+    SED_REQUIRE(pcm && tables && out, "logmel: null pointer");
+    SED_REQUIRE(n_fft == LM_NFFT, "logmel: n_fft must be %d (got %d)", LM_NFFT, n_fft);
+    SED_REQUIRE(n_samples > 0 && hop > 0 && n_mels > 0 && n_mels <= LM_MAX_MELS, "logmel: bad sizes");
+    SED_REQUIRE((mu == nullptr) == (inv_sigma == nullptr), "logmel: mu and inv_sigma go together");
+    SED_REQUIRE(pad_mode == 0 || pad_mode == 1, "logmel: pad_mode must be 0 (constant) or 1 (reflect)");
+    const int words = (int)(tables_bytes / 4);
+    SED_REQUIRE(tables_bytes % 16 == 0 && words >= LM_OFF_ENT + 64 + n_mels, "logmel: table blob of %zu bytes is malformed", tables_bytes);
+    const long frames = 1 + n_samples / hop;
+    hipStream_t s = as_stream(stream);
+    static const int wpb = getenv("SED_LOGMEL_WPB") ? atoi(getenv("SED_LOGMEL_WPB")) : 12;
+    if (wpb == 8) return launch_logmel<8>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
+    return launch_logmel<12>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
 }

@@ -34,29 +34,42 @@ def slaney_mel_basis(sr=SR, n_fft=NFFT, n_mels=NB_MEL):
     return tri.astype(np.float32)
 
 
+def hann_periodic(n_fft=NFFT):
+    """scipy.signal.get_window('hann', n_fft, fftbins=True) = librosa's default STFT window, float32"""
+    n = np.arange(n_fft, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).astype(np.float32)
+
+
 @functools.lru_cache(maxsize=8)
 def _tables(device_index, sr, n_fft, n_mels):
-    dev = torch.device("cuda", device_index)
-    n = np.arange(n_fft, dtype=np.float64)
-    window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).astype(np.float32)
-    k = np.arange(n_fft // 2, dtype=np.float64)
-    tw = np.stack([np.cos(2.0 * np.pi * k / n_fft), -np.sin(2.0 * np.pi * k / n_fft)], axis=1).astype(np.float32)
-    fb = slaney_mel_basis(sr, n_fft, n_mels)
-    return tuple(torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (window, tw, fb))
+    """the kernel's constant blob (window, FFT twiddles, sparse mel plan), built on the host by the library and copied
+    to the device once per (device, configuration)"""
+    import ctypes as C
+    window = np.ascontiguousarray(hann_periodic(n_fft))
+    fb = np.ascontiguousarray(slaney_mel_basis(sr, n_fft, n_mels))
+    hp = lambda a: C.c_void_p(a.ctypes.data)                                   # noqa: E731  host pointers
+    nbytes = lib().sed_logmel_tables_bytes(hp(fb), n_fft, n_mels)
+    if nbytes == 0:
+        check(-1, "sed_logmel_tables_bytes")
+    blob = np.zeros(nbytes // 4, dtype=np.uint32)
+    check(lib().sed_logmel_build_tables(hp(window), hp(fb), n_fft, n_mels, hp(blob), nbytes), "sed_logmel_build_tables")
+    return torch.from_numpy(blob.view(np.int32)).to(torch.device("cuda", device_index))
 
 
 def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=None, std=None):
     """y: mono float32 PCM CUDA tensor [N] -> [1 + N//hop, n_mels] log-mel energies (natural log, no eps)."""
     if not (isinstance(y, torch.Tensor) and y.is_cuda):
         raise RuntimeError("sed_crnn_amd.feature.mbe needs a CUDA(HIP) tensor; there is no CPU fallback")
+    if pad_mode not in ("constant", "reflect"):
+        raise ValueError(f"pad_mode must be 'constant' or 'reflect', got {pad_mode!r}")
     y = y.contiguous().float()
-    window, tw, fb = _tables(y.device.index or 0, sr, n_fft, n_mels)
+    tables = _tables(y.device.index or 0, sr, n_fft, n_mels)
     frames = 1 + y.numel() // hop
     out = torch.empty(frames, n_mels, device=y.device)
     inv = None
     if mean is not None:
         mean = mean.to(y.device).float().contiguous()
-        inv = (1.0 / std.to(y.device).float()).contiguous()
-    check(lib().sed_logmel(ptr(y), y.numel(), ptr(window), ptr(tw), ptr(fb), ptr(mean), ptr(inv), ptr(out), n_fft, hop,
+        inv = (1.0 / std.to(y.device).double()).float().contiguous()
+    check(lib().sed_logmel(ptr(y), y.numel(), ptr(tables), tables.numel() * 4, ptr(mean), ptr(inv), ptr(out), n_fft, hop,
                            n_mels, {"constant": 0, "reflect": 1}[pad_mode], stream_ptr()), "sed_logmel")
     return out
