@@ -40,30 +40,44 @@ def hann_periodic(n_fft=NFFT):
     return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).astype(np.float32)
 
 
-@functools.lru_cache(maxsize=8)
-def _tables(device_index, sr, n_fft, n_mels):
-    """the kernel's constant blob (window, FFT twiddles, sparse mel plan), built on the host by the library and copied
-    to the device once per (device, configuration)"""
+def build_tables(window, melfb, device):
+    """the kernel's constant blob (window, FFT twiddles, sparse mel plan) for an arbitrary window [n_fft] and filterbank
+    [n_mels, n_fft//2+1] (host arrays): built on the host by the library, then copied to ``device``"""
     import ctypes as C
-    window = np.ascontiguousarray(hann_periodic(n_fft))
-    fb = np.ascontiguousarray(slaney_mel_basis(sr, n_fft, n_mels))
+    window = np.ascontiguousarray(window, dtype=np.float32)
+    fb = np.ascontiguousarray(melfb, dtype=np.float32)
+    n_fft, n_mels = window.shape[0], fb.shape[0]
+    if fb.shape != (n_mels, n_fft // 2 + 1):
+        raise ValueError(f"filterbank must be [n_mels, {n_fft // 2 + 1}], got {fb.shape}")
     hp = lambda a: C.c_void_p(a.ctypes.data)                                   # noqa: E731  host pointers
     nbytes = lib().sed_logmel_tables_bytes(hp(fb), n_fft, n_mels)
     if nbytes == 0:
-        check(-1, "sed_logmel_tables_bytes")
+        raise ValueError(f"sed_logmel cannot plan this filterbank (n_fft must be {NFFT}, n_mels <= 128, and at most 8192 "
+                         f"non-zero weights so that the plan fits LDS); got n_fft={n_fft}, n_mels={n_mels}, "
+                         f"{int(np.count_nonzero(fb))} non-zeros")
     blob = np.zeros(nbytes // 4, dtype=np.uint32)
     check(lib().sed_logmel_build_tables(hp(window), hp(fb), n_fft, n_mels, hp(blob), nbytes), "sed_logmel_build_tables")
-    return torch.from_numpy(blob.view(np.int32)).to(torch.device("cuda", device_index))
+    return torch.from_numpy(blob.view(np.int32)).to(device)
 
 
-def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=None, std=None):
-    """y: mono float32 PCM CUDA tensor [N] -> [1 + N//hop, n_mels] log-mel energies (natural log, no eps)."""
+@functools.lru_cache(maxsize=8)
+def _tables(device_index, sr, n_fft, n_mels):
+    """librosa's defaults (periodic Hann, Slaney bank), cached per (device, configuration)"""
+    return build_tables(hann_periodic(n_fft), slaney_mel_basis(sr, n_fft, n_mels), torch.device("cuda", device_index))
+
+
+def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=None, std=None, tables=None):
+    """y: mono float32 PCM CUDA tensor [N] -> [1 + N//hop, n_mels] log-mel energies (natural log, no eps).
+    ``tables`` = build_tables(window, melfb, device) replaces librosa's default window / filterbank."""
     if not (isinstance(y, torch.Tensor) and y.is_cuda):
         raise RuntimeError("sed_crnn_amd.feature.mbe needs a CUDA(HIP) tensor; there is no CPU fallback")
     if pad_mode not in ("constant", "reflect"):
         raise ValueError(f"pad_mode must be 'constant' or 'reflect', got {pad_mode!r}")
     y = y.contiguous().float()
-    tables = _tables(y.device.index or 0, sr, n_fft, n_mels)
+    if tables is None:
+        tables = _tables(y.device.index or 0, sr, n_fft, n_mels)
+    else:
+        n_mels = int(tables[1])
     frames = 1 + y.numel() // hop
     out = torch.empty(frames, n_mels, device=y.device)
     inv = None

@@ -330,3 +330,47 @@ def test_logmel_vs_numpy_restatement(ops):
     out = feature.mbe(torch.from_numpy(y).cuda(), pad_mode="reflect", mean=torch.from_numpy(mu).float().cuda(),
                       std=torch.from_numpy(sd).float().cuda()).cpu().numpy()
     np.testing.assert_allclose(out, (ref - mu) / sd, atol=2e-3, rtol=1e-3)
+
+
+def test_logmel_edges_odd_hop_custom_bank_and_shift_invariance(ops):
+    """the cold paths of the log-mel kernel and two properties that hold at any length:
+    * signals shorter than one frame, an odd number of frames (the idle half wave), an odd hop (guarded loads);
+    * a filterbank that is NOT two-band (overlapping rectangles): the list plan; an all-zero band gives -inf (log 0);
+    * shifting the signal by one hop shifts the interior frames by one, bit for bit (same samples, same arithmetic)."""
+    from oracle import logmel_ref
+    from sed_crnn_amd import feature
+    rng = np.random.RandomState(5)
+    for n in (1, 700, 1024, 1025, 3 * 1024 + 7):
+        y = rng.randn(n).astype(np.float32)
+        for pad in ("constant", "reflect"):
+            if pad == "reflect" and n < 1025:
+                continue                                   # numpy cannot reflect-pad by more than the signal length
+            ref = logmel_ref.mbe(y, pad_mode=pad)
+            out = feature.mbe(torch.from_numpy(y).cuda(), pad_mode=pad).cpu().numpy()
+            assert out.shape == ref.shape == (1 + n // 1024, 40)
+            np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4, err_msg=f"n={n} {pad}")
+    y = rng.randn(9000).astype(np.float32)
+    ref = logmel_ref.mbe(y, hop=999)
+    out = feature.mbe(torch.from_numpy(y).cuda(), hop=999).cpu().numpy()
+    assert out.shape == ref.shape == (1 + 9000 // 999, 40)
+    np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4)
+    # custom bank: 12 overlapping rectangular bands of width 200 (three bands per bin) + one empty band
+    fb = np.zeros((13, 1025), np.float32)
+    for m in range(12):
+        fb[m, 70 * m: 70 * m + 200] = 1.0 / (m + 1)
+    win = logmel_ref.hann_periodic(2048)
+    tb = feature.build_tables(win, fb, "cuda")
+    assert int(tb[5]) == 0                                 # header word 5: the list plan was chosen
+    assert int(feature._tables(0, 44100, 2048, 40)[5]) == 1          # librosa's bank takes the two-band plan
+    y = rng.randn(8 * 1024).astype(np.float32)
+    p = logmel_ref.stft_power(y)
+    with np.errstate(divide="ignore"):
+        ref = np.log(p @ fb.T)
+    out = feature.mbe(torch.from_numpy(y).cuda(), tables=tb).cpu().numpy()
+    assert np.isneginf(out[:, 12]).all() and np.isneginf(ref[:, 12]).all()
+    np.testing.assert_allclose(out[:, :12], ref[:, :12], atol=1e-3, rtol=1e-4)
+    # shift invariance on a long signal (2 000 frames)
+    y = torch.randn(2000 * 1024 + 1024, generator=torch.Generator().manual_seed(1)).cuda()
+    a = feature.mbe(y)
+    b = feature.mbe(y[1024:].contiguous())
+    assert torch.equal(a[3:1990], b[2:1989])
