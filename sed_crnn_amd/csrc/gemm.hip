@@ -246,34 +246,79 @@ static int launch_gemm(bool akc, bool bkc, hipStream_t s, const float* A, long a
     return launch_gemm2<WVM, WVN, WM, WN, false, false>(grid, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv, k_len, slab);
 }
 
-// C[i][j] = sum_z slab[z][i][j] in slab order
-__global__ void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits, int M, int N, float* __restrict__ C, long ldc,
-                                     const float* __restrict__ bias) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long n = (long)M * N;
+// C[i][j] = sum_z slab[z][i][j] in slab order (+ bias); four consecutive elements per thread when the row length allows
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_k(const float* __restrict__ slabs, int splits, int M, int N,
+                                                            float* __restrict__ C, long ldc, const float* __restrict__ bias) {
+    const long n = (long)M * N;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    float a = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < splits; ++z) a += slabs[(size_t)z * n + i];
-    if (bias) a += bias[i % N];
-    C[(i / N) * ldc + (i % N)] = a;
+    if ((N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)slabs) & 15) == 0) {       // the 4 elements share a row; aligned 16-B accesses
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int z = 0; z < splits; ++z) a += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * n + i);
+        const long row = i / N, col = i - row * N;
+        if (bias) a += *reinterpret_cast<const f32x4*>(bias + col);
+        *reinterpret_cast<f32x4*>(C + row * ldc + col) = a;
+        return;
+    }
+    for (long e = i; e < i + 4 && e < n; ++e) {
+        float a = 0.f;
+        for (int z = 0; z < splits; ++z) a += slabs[(size_t)z * n + e];
+        if (bias) a += bias[e % N];
+        C[(e / N) * ldc + (e % N)] = a;
+    }
 }
 
-// Split-K plan for small-output / long-K products (the GRU weight gradients dW_hh, dW_ih of upper layers):
-// enough K-slices to give every CU a 64x64 tile; 1 = do not split.
-static int gemm_splits(int M, int N, int K) {
-    long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
-    if (blocks >= 96 || K < 1024) return 1;
-    int s = (int)(256 / blocks);
-    int maxs = K / 128;
-    if (s > maxs) s = maxs;
-    if (s > 32) s = 32;
-    return s < 2 ? 1 : s;
+// Tile + split-K plan.
+//  * tile: per-tile efficiency (register / LDS reuse) x how evenly the tiles fill whole rounds of the 256 CUs;
+//  * small-output / long-K products (the GRU weight gradients dW_hh, dW_ih of upper layers): 64x64 tiles and enough
+//    K-slices to give every CU one;
+//  * a product whose best tiling yields at most ~one tile per CU (the layer-0 input projection 4096x768x5120 = 256 tiles
+//    of 128x96, its weight gradient 768x5120x4096 = 240 tiles of 128x128) runs one 4-wave workgroup per CU, i.e. ONE wave per
+//    SIMD with nothing to cover its barrier and its LDS round trips (94 / 91 TFLOP/s against 117 for the 1280-tile data
+//    gradient that keeps several workgroups per CU): two K-slices make two co-resident workgroups per CU.
+//  Slices are summed in slice order by gemm_splitk_reduce_k: deterministic.
+struct GemmPlan { int cand, splits, k_len; };
+static const struct { int bm, bn; double eff; } kCands[5] = {{128, 128, 1.00}, {128, 96, 0.95}, {128, 64, 0.88}, {64, 128, 0.88}, {64, 64, 0.78}};
+
+static GemmPlan gemm_plan(int M, int N, int K, bool may_split) {
+    GemmPlan p = {4, 1, K};
+    const long blocks64 = (long)cdiv(M, 64) * cdiv(N, 64);
+    if (may_split && blocks64 < 96 && K >= 1024) {
+        int s = (int)(256 / blocks64);
+        const int maxs = K / 128;
+        if (s > maxs) s = maxs;
+        if (s > 32) s = 32;
+        if (s >= 2) {
+            p.k_len = ((cdiv(K, s) + GM_BK - 1) / GM_BK) * GM_BK;
+            p.splits = cdiv(K, p.k_len);
+            return p;
+        }
+    }
+    double best_score = -1.0;
+    long best_tiles = 0;
+    for (int i = 0; i < 5; ++i) {
+        if (kCands[i].bm > 64 && M <= 64) continue;
+        if (kCands[i].bn > 64 && N <= 64) continue;
+        const long tiles = (long)cdiv(M, kCands[i].bm) * cdiv(N, kCands[i].bn);
+        const double useful = ((double)M * N) / ((double)tiles * kCands[i].bm * kCands[i].bn);     // edge waste
+        const double rounds = (double)((tiles + 255) / 256);
+        double fill = tiles / (rounds * 256.0);
+        if (tiles >= 4 * 256) fill = fill > 0.9 ? fill : 0.9;                                      // many rounds: tail matters little
+        const double score = kCands[i].eff * useful * fill;
+        if (score > best_score) { best_score = score; p.cand = i; best_tiles = tiles; }
+    }
+    if (may_split && best_tiles > 128 && best_tiles <= 256 && K >= 2048 && (long)M * N >= (1L << 20)) {
+        p.k_len = ((cdiv(K, 2) + GM_BK - 1) / GM_BK) * GM_BK;
+        p.splits = cdiv(K, p.k_len);
+    }
+    return p;
 }
 
 extern "C" size_t sed_gemm_f32_workspace_bytes(int M, int N, int K) {
-    int s = gemm_splits(M, N, K);
-    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const GemmPlan p = gemm_plan(M, N, K, true);
+    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
 }
 
 static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
@@ -288,44 +333,28 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
     int bv = (((uintptr_t)B & 15) == 0) && ((bkc ? b_sj : b_sk) % 4 == 0);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_GEMM, s, 2.0 * M * (double)N * K);
-    const int splits = workspace ? gemm_splits(M, N, K) : 1;
-    if (splits > 1) {
-        SED_REQUIRE(beta == 0.f, "gemm_f32: split-K path takes no beta");
-        int k_len = ((cdiv(K, splits) + GM_BK - 1) / GM_BK) * GM_BK;
-        int rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, (float*)workspace, N, nullptr, 0.f, M, N, K, av, bv,
-                                   cdiv(K, k_len), k_len, (long)M * N);
-        if (rc) return rc;
-        SED_LAUNCH_CHECK("gemm_f32 (split-K)");
-        gemm_splitk_reduce_k<<<cdiv((long)M * N, 256), 256, 0, s>>>((const float*)workspace, cdiv(K, k_len), M, N, C, ldc, bias);
-        SED_LAUNCH_CHECK("gemm_splitk_reduce");
-        return 0;
-    }
-    // tile choice: per-tile efficiency (register / LDS reuse) x how evenly the tiles fill whole rounds of the 256 CUs
-    struct Cand { int bm, bn; double eff; };
-    const Cand cands[5] = {{128, 128, 1.00}, {128, 96, 0.95}, {128, 64, 0.88}, {64, 128, 0.88}, {64, 64, 0.78}};
-    int best = 4;
-    double best_score = -1.0;
-    for (int i = 0; i < 5; ++i) {
-        if (cands[i].bm > 64 && M <= 64) continue;
-        if (cands[i].bn > 64 && N <= 64) continue;
-        long tiles = (long)cdiv(M, cands[i].bm) * cdiv(N, cands[i].bn);
-        double useful = ((double)M * N) / ((double)tiles * cands[i].bm * cands[i].bn);     // edge waste
-        double rounds = (double)((tiles + 255) / 256);
-        double fill = tiles / (rounds * 256.0);
-        if (tiles >= 4 * 256) fill = fill > 0.9 ? fill : 0.9;                              // many rounds: tail matters little
-        double score = cands[i].eff * useful * fill;
-        if (score > best_score) { best_score = score; best = i; }
-    }
+    const GemmPlan p = gemm_plan(M, N, K, workspace != nullptr);
+    const bool split = p.splits > 1;
+    SED_REQUIRE(!split || beta == 0.f, "gemm_f32: split-K path takes no beta");
+    float* out = split ? (float*)workspace : C;
+    const long ldo = split ? N : ldc;
+    const float* ob = split ? nullptr : bias;
+    const long slab = split ? (long)M * N : 0;
     int rc;
-    switch (best) {
-        case 0: rc = launch_gemm<2, 2, 2, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
-        case 1: rc = launch_gemm<4, 1, 1, 3>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
-        case 2: rc = launch_gemm<2, 2, 2, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
-        case 3: rc = launch_gemm<2, 2, 1, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
-        default: rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, av, bv); break;
+    switch (p.cand) {
+        case 0: rc = launch_gemm<2, 2, 2, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, out, ldo, ob, beta, M, N, K, av, bv, p.splits, p.k_len, slab); break;
+        case 1: rc = launch_gemm<4, 1, 1, 3>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, out, ldo, ob, beta, M, N, K, av, bv, p.splits, p.k_len, slab); break;
+        case 2: rc = launch_gemm<2, 2, 2, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, out, ldo, ob, beta, M, N, K, av, bv, p.splits, p.k_len, slab); break;
+        case 3: rc = launch_gemm<2, 2, 1, 2>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, out, ldo, ob, beta, M, N, K, av, bv, p.splits, p.k_len, slab); break;
+        default: rc = launch_gemm<2, 2, 1, 1>(akc, bkc, s, A, a_si, a_sk, B, b_sk, b_sj, out, ldo, ob, beta, M, N, K, av, bv, p.splits, p.k_len, slab); break;
     }
     if (rc) return rc;
     SED_LAUNCH_CHECK("gemm_f32");
+    if (split) {
+        const long n4 = ((long)M * N + 3) / 4;
+        gemm_splitk_reduce_k<<<cdiv(n4, 256), 256, 0, s>>>((const float*)workspace, p.splits, M, N, C, ldc, bias);
+        SED_LAUNCH_CHECK("gemm_splitk_reduce");
+    }
     return 0;
 }
 

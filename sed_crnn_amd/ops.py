@@ -114,6 +114,9 @@ def gemm(A, B, bias=None, out=None, beta=0.0):
     return out
 
 
+_GEMM_WS = {}
+
+
 def gemm_ws(A, B, out=None, bias=None):
     """out = A @ B (+bias) through the split-K capable entry (workspace allocated here)."""
     M, K = A.shape
@@ -121,7 +124,10 @@ def gemm_ws(A, B, out=None, bias=None):
     if out is None:
         out = torch.empty(M, N, device=A.device)
     nb = lib().sed_gemm_f32_workspace_bytes(M, N, K)
-    ws = torch.empty(nb // 4 + 1, device=A.device) if nb else None
+    key = (A.device, nb)
+    ws = _GEMM_WS.get(key) if nb else None
+    if nb and ws is None:
+        ws = _GEMM_WS[key] = torch.empty(nb // 4 + 1, device=A.device)
     check(lib().sed_gemm_f32_ws(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
                                 out.stride(0), ptr(bias), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_ws")
     return out
