@@ -156,9 +156,15 @@ int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk
  * gradients, M*N small, K = B*T'; the input projection of a small batch, M = B*T' small, K = C*F') would leave most
  * CUs without a tile, so they are split along K into fixed slices that are summed in slice order (deterministic; the
  * bias is added by the summing pass).  workspace >= sed_gemm_f32_workspace_bytes(M,N,K) (0 = the shape is not split). */
-size_t sed_gemm_f32_workspace_bytes(int M, int N, int K);
+size_t sed_gemm_f32_workspace_bytes(int M, int N, int K);   /* covers sed_gemm_f32_ws and sed_gemm_f32_wgrad */
 int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
                     float* C, long ldc, const float* bias, int M, int N, int K, void* workspace, void* stream);
+
+/* Weight-gradient form (dW = dY^T X under loss.backward(), sed.py:137): the same product, beta = 0, no bias, whose K axis is
+ * the batch x time axis.  Besides the small-output split above it may be cut into two K-slices when its best tiling
+ * gives at most one tile per CU (two co-resident workgroups per CU instead of one).  Deterministic for given (M,N,K). */
+int sed_gemm_f32_wgrad(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj,
+                       float* C, long ldc, int M, int N, int K, void* workspace, void* stream);
 
 /* Small dense layer y = act(x W^T + b) for the time-distributed head (sed.py:103,112;
  * crnn_lightning.py:63-64,72-73). x [M][K], W [N][K], y [M][N]; relu=1 applies ReLU. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "sed_gemm_f32": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _fp, _f, _i, _i, _i, _stream]),
     "sed_gemm_f32_workspace_bytes": (_sz, [_i, _i, _i]),
     "sed_gemm_f32_ws": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _fp, _i, _i, _i, _fp, _stream]),
+    "sed_gemm_f32_wgrad": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _i, _i, _i, _fp, _stream]),
     "sed_linear_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),
     "sed_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "sed_linear_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _stream]),

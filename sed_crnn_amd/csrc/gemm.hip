@@ -273,15 +273,20 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_k(const float* __restr
 //  * tile: per-tile efficiency (register / LDS reuse) x how evenly the tiles fill whole rounds of the 256 CUs;
 //  * small-output / long-K products (the GRU weight gradients dW_hh, dW_ih of upper layers): 64x64 tiles and enough
 //    K-slices to give every CU one;
-//  * a product whose best tiling yields at most ~one tile per CU (the layer-0 input projection 4096x768x5120 = 256 tiles
-//    of 128x96, its weight gradient 768x5120x4096 = 240 tiles of 128x128) runs one 4-wave workgroup per CU, i.e. ONE wave per
-//    SIMD with nothing to cover its barrier and its LDS round trips (94 / 91 TFLOP/s against 117 for the 1280-tile data
-//    gradient that keeps several workgroups per CU): two K-slices make two co-resident workgroups per CU.
+//  * a product whose best tiling yields at most ~one tile per CU (the layer-0 weight gradient 768x5120x4096 = 240 tiles of
+//    128x128) runs one 4-wave workgroup per CU, i.e. ONE wave per SIMD with nothing to cover its barrier and its LDS round
+//    trips (91 TFLOP/s against 117 for the 1280-tile data gradient that keeps several workgroups per CU): two K-slices make
+//    two co-resident workgroups per CU (113 TFLOP/s incl. the slice sum).  Weight gradients only (sed_gemm_f32_wgrad): their K
+//    axis is the batch x time axis, so no caller can expect the result to be independent of how that axis is cut.  The
+//    forward input projection (same shape class, +15 % with two slices) is NOT sliced: an eval forward of a whole batch must
+//    stay bit-identical to the forward of its chunks.
 //  Slices are summed in slice order by gemm_splitk_reduce_k: deterministic.
 struct GemmPlan { int cand, splits, k_len; };
 static const struct { int bm, bn; double eff; } kCands[5] = {{128, 128, 1.00}, {128, 96, 0.95}, {128, 64, 0.88}, {64, 128, 0.88}, {64, 64, 0.78}};
 
-static GemmPlan gemm_plan(int M, int N, int K, bool may_split) {
+// policy 0: never split; 1: small-output split only; 2: also the two-slice rule (weight gradients)
+static GemmPlan gemm_plan(int M, int N, int K, int policy) {
+    const bool may_split = policy >= 1;
     GemmPlan p = {4, 1, K};
     const long blocks64 = (long)cdiv(M, 64) * cdiv(N, 64);
     if (may_split && blocks64 < 96 && K >= 1024) {
@@ -308,7 +313,7 @@ static GemmPlan gemm_plan(int M, int N, int K, bool may_split) {
         const double score = kCands[i].eff * useful * fill;
         if (score > best_score) { best_score = score; p.cand = i; best_tiles = tiles; }
     }
-    if (may_split && best_tiles > 128 && best_tiles <= 256 && K >= 2048 && (long)M * N >= (1L << 20)) {
+    if (policy >= 2 && best_tiles > 128 && best_tiles <= 256 && K >= 2048 && (long)M * N >= (1L << 20)) {
         p.k_len = ((cdiv(K, 2) + GM_BK - 1) / GM_BK) * GM_BK;
         p.splits = cdiv(K, p.k_len);
     }
@@ -317,12 +322,17 @@ static GemmPlan gemm_plan(int M, int N, int K, bool may_split) {
 
 extern "C" size_t sed_gemm_f32_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const GemmPlan p = gemm_plan(M, N, K, true);
-    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    size_t best = 0;
+    for (int policy = 1; policy <= 2; ++policy) {
+        const GemmPlan p = gemm_plan(M, N, K, policy);
+        const size_t b = p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
-                     long ldc, const float* bias, float beta, int M, int N, int K, void* workspace, void* stream) {
+                     long ldc, const float* bias, float beta, int M, int N, int K, void* workspace, int policy, void* stream) {
     SED_REQUIRE(A && B && C, "gemm_f32: null pointer");
     SED_REQUIRE(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm_f32: bad sizes M=%d N=%d K=%d ldc=%ld", M, N, K, ldc);
     SED_REQUIRE(a_si == 1 || a_sk == 1, "gemm_f32: A must be contiguous along i or k (strides %ld,%ld)", a_si, a_sk);
@@ -333,7 +343,7 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
     int bv = (((uintptr_t)B & 15) == 0) && ((bkc ? b_sj : b_sk) % 4 == 0);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_GEMM, s, 2.0 * M * (double)N * K);
-    const GemmPlan p = gemm_plan(M, N, K, workspace != nullptr);
+    const GemmPlan p = gemm_plan(M, N, K, workspace ? policy : 0);
     const bool split = p.splits > 1;
     SED_REQUIRE(!split || beta == 0.f, "gemm_f32: split-K path takes no beta");
     float* out = split ? (float*)workspace : C;
@@ -360,12 +370,17 @@ static int gemm_impl(const float* A, long a_si, long a_sk, const float* B, long 
 
 extern "C" int sed_gemm_f32(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
                             long ldc, const float* bias, float beta, int M, int N, int K, void* stream) {
-    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, nullptr, stream);
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, beta, M, N, K, nullptr, 0, stream);
 }
 
 extern "C" int sed_gemm_f32_ws(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
                                long ldc, const float* bias, int M, int N, int K, void* workspace, void* stream) {
-    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, 0.f, M, N, K, workspace, stream);
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, bias, 0.f, M, N, K, workspace, 1, stream);
+}
+
+extern "C" int sed_gemm_f32_wgrad(const float* A, long a_si, long a_sk, const float* B, long b_sk, long b_sj, float* C,
+                                  long ldc, int M, int N, int K, void* workspace, void* stream) {
+    return gemm_impl(A, a_si, a_sk, B, b_sk, b_sj, C, ldc, nullptr, 0.f, M, N, K, workspace, 2, stream);
 }
 
 // ───────────────────────── small dense head ─────────────────────────

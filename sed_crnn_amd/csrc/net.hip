@@ -76,7 +76,9 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         if (q.fused) c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
         else {
             size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
-            if (wg > max_wgrad) max_wgrad = wg;
+            // block 0's weight gradient runs on the auxiliary stream beside the MFMA weight gradients: its own scratch
+            if (l == 0 && c->n_conv > 1) c1_ws = wg + 64;
+            else if (wg > max_wgrad) max_wgrad = wg;
         }
         if (q.bn_rows > max_bn_rows) max_bn_rows = q.bn_rows;
         if (q.C > maxC) maxC = q.C;
@@ -370,8 +372,8 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             float* dbhh[2] = {g->gru_bhh[i][0], g->gru_bhh[i][1]};
             SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, dbih, dbhh, ws + L.gru_bws, B, L.Tp, H, stream));
             for (int d = 0; d < 2; ++d)      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
-                SED_TRY(sed_gemm_f32_ws(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
-                                        g->gru_whh[i][d], H, nullptr, 3 * H, H, M, ws + L.gemm_ws, stream));
+                SED_TRY(sed_gemm_f32_wgrad(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
+                                           g->gru_whh[i][d], H, 3 * H, H, M, ws + L.gemm_ws, stream));
             const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
                                g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
             // data gradient first: for layer 0 it is the input of the top conv block's BatchNorm backward, which then runs
@@ -391,7 +393,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 (void)hipEventRecord(ev_bn[top], s_aux);
             }
             if (fused) {
-                SED_TRY(sed_gemm_f32_ws(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, nullptr, 6 * H, K, M, ws + L.gemm_ws, stream));
+                SED_TRY(sed_gemm_f32_wgrad(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
             } else {
                 for (int d = 0; d < 2; ++d)
                     SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
@@ -406,11 +408,16 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     // leaves it).  BN of blocks 1..top-1 runs alone on the main stream (co-running it with a weight gradient stretched
     // it to the whole window and hid nothing); BN(top) was issued by stage 0 beside the GRU weight-gradient GEMM.
     auto bn_passes = [&](int l, void* st) -> int { return bn_backward(L, c, p, g, x, ws, seed, seed_dev, l, 3, 1.f, st); };
-    auto wgrad = [&](int l) -> int {
+    auto wgrad_on = [&](int l, void* st) -> int {
         const ConvL& q = L.cv[l];
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
-        return sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream);
+        float* scratch = ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws);
+        return sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, st);
     };
+    auto wgrad = [&](int l) -> int { return wgrad_on(l, stream); };
+    // an unfused first block (Cin > 2): its HBM-bound weight gradient follows its BatchNorm backward on the same stream, so with
+    // an auxiliary stream it hides behind the MFMA weight gradients too instead of trailing them on the main stream
+    const bool wg0_with_bn = L.n_conv > 1 && !L.cv[0].fused;
     const int top = L.n_conv - 1;
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
@@ -422,7 +429,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             (void)hipStreamWaitEvent(s_main, ev_bn[0], 0);
         }
         if (l == 0) {
-            if (!q.fused) SED_TRY(wgrad(0));         // fused block 0: its BN pass already produced every gradient
+            if (!q.fused && !wg0_with_bn) SED_TRY(wgrad(0));     // fused block 0: its BN pass already produced every gradient
             continue;
         }
         // data gradient = the same convolution with flipped, transposed taps
@@ -435,9 +442,11 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             (void)hipEventRecord(ev_dg[0], s_main);
             (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
             SED_TRY(bn_passes(0, aux_stream));
+            if (wg0_with_bn) SED_TRY(wgrad_on(0, aux_stream));
             (void)hipEventRecord(ev_bn[0], s_aux);
         } else {
             SED_TRY(bn_passes(0, stream));
+            if (wg0_with_bn) SED_TRY(wgrad_on(0, stream));
         }
         for (int k = top; k >= 1; --k) SED_TRY(wgrad(k));
     }
@@ -471,7 +480,8 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
         SED_TRY(bn_backward(L, c, p, g, x, ws, seed, nullptr, l, 2, count_scale, stream));
         if (q.fused) continue;
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
-        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws, B, q.Cin, q.F, q.T, q.C, stream));
+        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
+                                  B, q.Cin, q.F, q.T, q.C, stream));
         if (l > 0)
             SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
     }

@@ -117,8 +117,9 @@ def gemm(A, B, bias=None, out=None, beta=0.0):
 _GEMM_WS = {}
 
 
-def gemm_ws(A, B, out=None, bias=None):
-    """out = A @ B (+bias) through the split-K capable entry (workspace allocated here)."""
+def gemm_ws(A, B, out=None, bias=None, wgrad=False):
+    """out = A @ B (+bias) through the split-K capable entries (workspace cached here); wgrad=True: the weight-gradient
+    entry, which may also cut a one-tile-per-CU product into two K-slices"""
     M, K = A.shape
     _, N = B.shape
     if out is None:
@@ -128,6 +129,11 @@ def gemm_ws(A, B, out=None, bias=None):
     ws = _GEMM_WS.get(key) if nb else None
     if nb and ws is None:
         ws = _GEMM_WS[key] = torch.empty(nb // 4 + 1, device=A.device)
+    if wgrad:
+        assert bias is None
+        check(lib().sed_gemm_f32_wgrad(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
+                                       out.stride(0), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_wgrad")
+        return out
     check(lib().sed_gemm_f32_ws(ptr(A), A.stride(0), A.stride(1), ptr(B), B.stride(0), B.stride(1), ptr(out),
                                 out.stride(0), ptr(bias), M, N, K, ptr(ws), stream_ptr()), "gemm_f32_ws")
     return out

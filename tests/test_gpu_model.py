@@ -641,3 +641,56 @@ def test_full_size_multichannel_configs_finite_separable_deterministic(sed, name
     assert torch.equal(whole, parts)
     del m, x, y, p0, p1, p2, g1, g2
     torch.cuda.empty_cache()
+
+
+def test_forty_step_trajectory_is_as_close_to_float64_as_torch_float32_is(sed):
+    """Separates "two fp32 trajectories drift apart" from a real defect (round-1 verdict).  The 40-step run of
+    test_forty_step_trajectory_tracks_the_oracle_and_scores_agree is repeated a third time in FLOAT64 (the oracle net cast
+    to double): that run is the yardstick.  Freezing the zero-gradient conv biases alone does not stop the drift (measured:
+    weights still 2e-3 apart, max |dp| 3e-2), so the drift is Adam's amplification of rounding noise on EVERY coordinate
+    with a small gradient, and the question becomes whether the HIP path is any further from the float64 truth than torch's
+    own float32 path is.  Asserted: per-step losses and final probabilities of the HIP run are within 3x torch-float32's
+    own distance from float64 (plus a small floor), i.e. the HIP path is an fp32 implementation of the same computation,
+    not a different one."""
+    from oracle import crnn_ref
+    from sed_crnn_amd.trainer import FusedTrainStep
+    torch.manual_seed(99)
+    kw = dict(conv_channels=16, dropout=0.0, gru_hidden=16)
+    ref32 = crnn_ref.SedNetRef(**kw)
+    ref64 = crnn_ref.SedNetRef(**kw).double()
+    ref64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in ref32.state_dict().items()})
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref32.state_dict())
+    m.cuda()
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(4):
+        x = torch.randn(16, 1, 40, 64, generator=g)
+        band = x[:, 0, 8:16, :].mean(1)
+        y = (band.reshape(16, 8, 8).amax(2) > 0.45).float().unsqueeze(-1)
+        batches.append((x, y))
+    o32 = torch.optim.Adam(ref32.parameters(), lr=2e-3)
+    o64 = torch.optim.Adam(ref64.parameters(), lr=2e-3)
+    step = FusedTrainStep(m, lr=2e-3, loss="bce")
+    l32, l64, lh = [], [], []
+    for it in range(40):
+        x, y = batches[it % 4]
+        l32.append(float(crnn_ref.fit_step(ref32, o32, x, y)[0]))
+        l64.append(float(crnn_ref.fit_step(ref64, o64, x.double(), y.double())[0]))
+        lh.append(step.step(x.cuda(), y.cuda())[0])
+    lh = torch.stack([l.reshape(()) for l in lh]).cpu().numpy().astype(np.float64)
+    l32, l64 = np.asarray(l32), np.asarray(l64)
+    xs = torch.cat([b[0] for b in batches])
+    for net in (ref32, ref64, m):
+        net.eval()
+    with torch.no_grad():
+        p32 = torch.sigmoid(ref32(xs)).double().numpy()
+        p64 = torch.sigmoid(ref64(xs.double())).numpy()
+        ph = torch.sigmoid(m(xs.cuda())).cpu().double().numpy()
+    e_loss_t, e_loss_h = np.abs(l32 - l64).max(), np.abs(lh - l64).max()
+    e_p_t, e_p_h = np.abs(p32 - p64), np.abs(ph - p64)
+    print(f"distance from the float64 run after 40 Adam steps: loss torch-f32 {e_loss_t:.2e} / HIP {e_loss_h:.2e}; "
+          f"probabilities max torch-f32 {e_p_t.max():.2e} / HIP {e_p_h.max():.2e}, mean {e_p_t.mean():.2e} / {e_p_h.mean():.2e}")
+    assert e_loss_h <= 3.0 * e_loss_t + 1e-4
+    assert e_p_h.mean() <= 3.0 * e_p_t.mean() + 1e-4
+    assert e_p_h.max() <= 3.0 * e_p_t.max() + 1e-3

@@ -55,9 +55,8 @@ def main():
         dW = torch.empty(6 * H, K, device=dev)
         dX = torch.empty(M, K, device=dev)
         cases = [("fwd  X[4096,5120] @ W^T[5120,768]", lambda: ops.gemm(X, W.t(), out=out), 2 * M * K * 6 * H),
-                 ("fwd  (workspace entry: split-K plan)", lambda: ops.gemm_ws(X, W.t(), out=out), 2 * M * K * 6 * H),
                  ("dW   dgi^T[768,4096] @ X[4096,5120]", lambda: ops.gemm(dgi.t(), X, out=dW), 2 * M * K * 6 * H),
-                 ("dW   (workspace entry: split-K plan)", lambda: ops.gemm_ws(dgi.t(), X, out=dW), 2 * M * K * 6 * H),
+                 ("dW   (weight-gradient entry: two K-slices)", lambda: ops.gemm_ws(dgi.t(), X, out=dW, wgrad=True), 2 * M * K * 6 * H),
                  ("dX   dgi[4096,768] @ W[768,5120]", lambda: ops.gemm(dgi, W, out=dX), 2 * M * K * 6 * H)]
         X1 = torch.randn(M, 256, device=dev)
         W1 = torch.randn(768, 256, device=dev)
