@@ -136,22 +136,40 @@ def _free_port():
 
 
 def launch_ranks(n, argv):
-    """Start n fresh rank processes of this script.  The launcher has not imported torch and makes no GPU call."""
+    """Start n fresh rank processes of this script and forward rank 0's output.  The launcher has not imported torch and
+    makes no GPU call.  If one rank dies the others would wait in the rendezvous or in a collective until their timeout:
+    the launcher ends exactly the processes it started (by handle, never by pattern) as soon as one of them has failed."""
+    import tempfile
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(line.decode())
-    sys.stdout.flush()
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"[bench] rank processes failed: {bad}", file=sys.stderr)
-        return max(abs(c) for _, c in bad) or 1
+    if bad or failed:
+        print(f"[bench] rank processes failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
     return 0
 
 
@@ -301,7 +319,7 @@ def run_rank(args):
                                                f"command (profiles/{rnd}): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
                                "flops_per_launch_avg": units.value / n.value}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:              # rank 0 at N = 1 only (a reported baseline, not part of the step)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
