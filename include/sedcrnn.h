@@ -126,10 +126,14 @@ int sed_reduce_rows(const float* partials, int rows, int C, int row_stride, floa
  * the step.  These four entries replace sed_conv3x3_fwd + the bn_* entries + sed_conv3x3_wgrad for block 1 and
  * recompute conv(x) on the fly, so that tensor never exists in HBM.  x [B][Cin][F][T] (network input layout),
  * wp = [9][C][Cin] from sed_conv3x3_pack_weights, pooled output / dout channels-last [B][T/pt][F/pf][C].
- * rows = sed_conv1_fused_rows(B,T) partial rows for stats ([rows][2][C]) and bwd_reduce ([rows][2][C]). */
+ * rows = sed_conv1_fused_rows(B,T) partial rows for bwd_reduce ([rows][2][C]); the statistics are one row. */
 int sed_conv1_fused_supported(int Cin, int F, int T, int C, int pool_f, int pool_t);   /* 1 = shapes accepted */
 int sed_conv1_fused_rows(int B, int T);
-int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials,
+/* Statistics WITHOUT recomputing the convolution: sum y and sum y^2 of every output channel follow from the first and
+ * second moments of the 9*Cin shifted inputs (one pass over x, fp64 quadratic form per channel).  Writes ONE partial
+ * row [1][2][C]; workspace >= sed_conv1_stats_workspace_bytes(). */
+size_t sed_conv1_stats_workspace_bytes(int B, int Cin, int T);
+int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials, void* workspace,
                     int B, int Cin, int F, int T, int C, void* stream);
 int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
                                     const float* shift, float* out, int B, int Cin, int F, int T, int C,

@@ -20,7 +20,7 @@ struct Layout {
     // float offsets into the workspace
     size_t wp_f[SED_MAX_CONV], wp_d[SED_MAX_CONV], conv_out[SED_MAX_CONV], stat[SED_MAX_CONV];
     size_t mean[SED_MAX_CONV], rstd[SED_MAX_CONV], scale[SED_MAX_CONV], shift[SED_MAX_CONV];
-    size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV];
+    size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV], c1_stat_ws;
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
@@ -44,7 +44,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
     Carver cv;
     int Cin = c->Cin, T = c->T, F = c->F;
-    size_t max_pool = 0, max_wgrad = 0, c1_ws = 64;
+    size_t max_pool = 0, max_wgrad = 0, c1_ws = 64, c1_stat_ws = 64;
     int max_bn_rows = 0, maxC = 0;
     for (int l = 0; l < c->n_conv; ++l) {
         ConvL& q = L->cv[l];
@@ -58,7 +58,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         // block 1 with <= 2 input channels: the conv output is recomputed in every pass and never stored (conv1.hip)
         q.fused = (l == 0 && c->n_conv > 1 && sed_conv1_fused_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt)) ? 1 : 0;
         if (q.fused) {
-            q.rows = q.bn_rows = sed_conv1_fused_rows(c->B, q.T);
+            q.rows = 1;                                        // statistics from the input moments: one partial row
+            q.bn_rows = sed_conv1_fused_rows(c->B, q.T);
         } else {
             q.rows = sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
             SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
@@ -73,8 +74,11 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->pooled[l] = cv.take(npool);
         L->bn_sums[l] = cv.take((size_t)2 * q.C);
         if (npool > max_pool) max_pool = npool;
-        if (q.fused) c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
-        else {
+        if (q.fused) {
+            c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
+            const size_t sws = sed_conv1_stats_workspace_bytes(c->B, q.Cin, q.T) / sizeof(float);
+            if (sws > c1_stat_ws) c1_stat_ws = sws;
+        } else {
             size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
             // block 0's weight gradient runs on the auxiliary stream beside the MFMA weight gradients: its own scratch
             if (l == 0 && c->n_conv > 1) c1_ws = wg + 64;
@@ -84,6 +88,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         if (q.C > maxC) maxC = q.C;
         Cin = q.C; T = q.Tp; F = q.Fp;
     }
+    L->c1_stat_ws = cv.take(c1_stat_ws);
     L->Tp = T; L->Fp = F; L->feat = Cin * F; L->M = c->B * T;
     const size_t M = (size_t)L->M;
     int in = L->feat, maxH = 0, max2H = 0;
@@ -184,7 +189,7 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
             SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
                                              q.C, q.Cin, stream));
             if (q.fused) {
-                if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], B, q.Cin, q.F, q.T, q.C, stream));
+                if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C, stream));
             } else {
                 SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
                                         training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));

@@ -238,8 +238,9 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
     assert L.sed_conv1_fused_supported(Cin, F, T, Cc, pool_f, pool_t)
     wf, _ = conv3x3_pack(w)
     rows = L.sed_conv1_fused_rows(B, T)
-    stat = torch.empty(rows, 2, Cc, device=x.device)
-    check(L.sed_conv1_stats(ptr(_f32c(x)), ptr(wf), ptr(bias), ptr(stat), B, Cin, F, T, Cc, stream_ptr()), "conv1_stats")
+    stat = torch.empty(1, 2, Cc, device=x.device)
+    sws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, Cin, T) // 4 + 1, device=x.device)
+    check(L.sed_conv1_stats(ptr(_f32c(x)), ptr(wf), ptr(bias), ptr(stat), ptr(sws), B, Cin, F, T, Cc, stream_ptr()), "conv1_stats")
     rm, rv = torch.zeros(Cc, device=x.device), torch.ones(Cc, device=x.device)
     mean, rstd, scale, shift = bn_finalize_train(stat, B * T * F, gamma, beta, rm, rv, eps=eps)
     out = torch.empty(B, T // pool_t, F // pool_f, Cc, device=x.device)

