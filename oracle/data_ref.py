@@ -67,3 +67,31 @@ def split_multi_channels(data, num_channels):
     for c in range(num_channels):
         out[:, c] = data[:, :, c * hop:(c + 1) * hop]
     return out
+
+
+def rasterize_hits_ref(n_frames, hits, sr=44100, hop=1024):
+    """label raster of /root/reference/feature.py:89-93"""
+    lbl = np.zeros((n_frames, 1), dtype=np.float32)
+    for start, end in hits:
+        lbl[int(np.floor(start * sr / hop)):int(np.ceil(end * sr / hop)), 0] = 1.0
+    return lbl
+
+
+def build_fold_packs_ref(per_video):
+    """per-fold train / test concatenation + StandardScaler of /root/reference/feature.py:113-129 (numpy; the scaler is the
+    sklearn-pinned restatement of oracle.logmel_ref).  -> {fold_number: (X_train, Y_train, X_test, Y_test)}"""
+    from .logmel_ref import standardize_apply, standardize_fit
+    fold_k = max(v[2] for v in per_video.values()) + 1
+    out = {}
+    for f in range(fold_k):
+        xtr = ytr = xte = yte = None
+        for _, (mbe, lbl, fold) in per_video.items():
+            if fold == f:
+                xte = mbe if xte is None else np.concatenate((xte, mbe), axis=0)
+                yte = lbl if yte is None else np.concatenate((yte, lbl), axis=0)
+            else:
+                xtr = mbe if xtr is None else np.concatenate((xtr, mbe), axis=0)
+                ytr = lbl if ytr is None else np.concatenate((ytr, lbl), axis=0)
+        mean, scale = standardize_fit(xtr)
+        out[f + 1] = (standardize_apply(xtr, mean, scale), ytr, standardize_apply(xte, mean, scale), yte)
+    return out

@@ -87,3 +87,61 @@ def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=
     check(lib().sed_logmel(ptr(y), y.numel(), ptr(tables), tables.numel() * 4, ptr(mean), ptr(inv), ptr(out), n_fft, hop,
                            n_mels, {"constant": 0, "reflect": 1}[pad_mode], stream_ptr()), "sed_logmel")
     return out
+
+
+# ───────────────────────── feature.py's on-disk formats ─────────────────────────
+def rasterize_hits(n_frames, hits, sr=SR, hop=HOP):
+    """Frame labels of one recording from its hit intervals in seconds (feature.py:89-93): frames
+    [floor(start*sr/hop), ceil(end*sr/hop)) are 1.  -> float32 [n_frames, 1]"""
+    lbl = np.zeros((n_frames, 1), dtype=np.float32)
+    for start, end in hits:
+        s = int(np.floor(start * sr / hop))
+        e = int(np.ceil(end * sr / hop))
+        lbl[s:e, 0] = 1.0
+    return lbl
+
+
+def save_video_npz(path, mbe_frames, labels):
+    """per-recording cache `{base}_mon.npz` (feature.py:72,95): positional arr_0 = features [n, n_mels], arr_1 = labels [n, 1]"""
+    np.savez(path, np.asarray(mbe_frames, dtype=np.float32), np.asarray(labels, dtype=np.float32))
+
+
+def load_video_npz(path):
+    with np.load(path, allow_pickle=False) as d:
+        if "arr_0" not in d.files or "arr_1" not in d.files:
+            raise ValueError(f"{path}: not a per-recording cache (feature.py:95 saves two positional arrays)")
+        mbe_frames, labels = d["arr_0"], d["arr_1"]
+    if mbe_frames.shape[0] != labels.shape[0]:
+        raise ValueError(f"{path}: {mbe_frames.shape[0]} feature frames but {labels.shape[0]} label frames")
+    return mbe_frames, labels
+
+
+def build_fold_packs(per_video, cache_dir, device="cuda"):
+    """feature.py:114-132 on the device: for every fold f the recordings of fold f are the test split and all others the
+    train split (concatenated in dict order), a StandardScaler is fitted on the train split and applied to both
+    (`data.standard_scaler_fit` / `standard_scaler_transform`: sklearn's rules, float64 statistics), and the pack is saved
+    as `mbe_mon_fold{f+1}.npz` with the positional arrays X_train, Y_train, X_test, Y_test that sed.py:119-123 reads.
+    ``per_video``: {name: (features [n, F] host or device, labels [n, 1], fold_id)}.  Returns the written paths."""
+    import os
+    from .data import standard_scaler_fit, standard_scaler_transform
+    folds = max(v[2] for v in per_video.values()) + 1
+    dev = torch.device(device)
+    as_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev).float()   # noqa: E731
+    feats = {k: (as_dev(v[0]), np.asarray(v[1].cpu() if isinstance(v[1], torch.Tensor) else v[1], dtype=np.float32), v[2])
+             for k, v in per_video.items()}
+    os.makedirs(cache_dir, exist_ok=True)
+    paths = []
+    for f in range(folds):
+        test = [v for v in feats.values() if v[2] == f]
+        train = [v for v in feats.values() if v[2] != f]
+        if not test or not train:
+            raise ValueError(f"fold {f} has {len(test)} test and {len(train)} train recordings")
+        x_train, x_test = torch.cat([v[0] for v in train]), torch.cat([v[0] for v in test])
+        mean, scale = standard_scaler_fit(x_train)
+        x_train = standard_scaler_transform(x_train, mean, scale, out=x_train)
+        x_test = standard_scaler_transform(x_test, mean, scale, out=x_test)
+        path = os.path.join(cache_dir, f"mbe_mon_fold{f + 1}.npz")
+        np.savez(path, x_train.cpu().numpy(), np.concatenate([v[1] for v in train]), x_test.cpu().numpy(),
+                 np.concatenate([v[1] for v in test]))
+        paths.append(path)
+    return paths

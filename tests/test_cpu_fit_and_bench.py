@@ -155,3 +155,28 @@ def test_scaler_oracle_reproduces_the_sklearn_golden():
     assert 0 < scale[5] < 1e-9                                       # constant up to ONE float32 ulp: sklearn keeps sigma
     np.testing.assert_array_equal(logmel_ref.standardize_apply(xtr, mean, scale), d["train_t"])
     np.testing.assert_array_equal(logmel_ref.standardize_apply(xte, mean, scale), d["test_t"])
+
+
+# ───────────────────────── feature.py's per-recording cache and label raster ─────────────────────────
+def test_label_raster_and_per_recording_cache_format(tmp_path):
+    from oracle import data_ref
+    from sed_crnn_amd import feature
+    hits = [(0.0, 0.05), (1.0, 1.2), (2.32, 2.33), (9.9, 10.5)]
+    n = 440
+    lbl = feature.rasterize_hits(n, hits)
+    np.testing.assert_array_equal(lbl, data_ref.rasterize_hits_ref(n, hits))
+    assert lbl.shape == (n, 1) and lbl.dtype == np.float32
+    assert lbl[:3, 0].tolist() == [1, 1, 1] and lbl[3, 0] == 0                     # [floor(0), ceil(0.05*43.07)=3)
+    assert lbl[43, 0] == 1 and lbl[42, 0] == 0 and lbl[51, 0] == 1 and lbl[52, 0] == 0   # 1.0 s .. 1.2 s
+    assert lbl[426:, 0].all() and lbl.sum() == 3 + 9 + 2 + 14                      # the last hit is clipped at the end
+    mbe = np.random.default_rng(0).standard_normal((n, 40)).astype(np.float32)
+    path = str(tmp_path / "rec01_mon.npz")
+    feature.save_video_npz(path, mbe, lbl)
+    with np.load(path) as d:
+        assert d.files == ["arr_0", "arr_1"]                                        # what feature.py:75-76 reads back
+    a, b = feature.load_video_npz(path)
+    np.testing.assert_array_equal(a, mbe)
+    np.testing.assert_array_equal(b, lbl)
+    np.savez(tmp_path / "bad_mon.npz", mbe, lbl[:-1])
+    with pytest.raises(ValueError, match="label frames"):
+        feature.load_video_npz(str(tmp_path / "bad_mon.npz"))

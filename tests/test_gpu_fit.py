@@ -285,3 +285,30 @@ def test_workspace_of_a_captured_graph_survives_other_shapes(sed):
     with pytest.raises(RuntimeError, match="rebuilt"):
         m.cuda().cpu().cuda()
         st.step(x, y)
+
+
+def test_build_fold_packs_matches_the_reference_pipeline_and_feeds_the_loader(sed, tmp_path):
+    """feature.py:113-132 on the device (per-fold concatenation, scaler fitted on the train split, positional npz) against
+    the numpy restatement with the sklearn-pinned scaler; the packs are then read back by load_all_npz"""
+    from oracle import data_ref
+    from sed_crnn_amd import data, feature
+    rng = np.random.default_rng(8)
+    per_video = {}
+    for i in range(9):
+        n = int(rng.integers(150, 400))
+        mbe = (rng.standard_normal((n, 40)) * rng.uniform(0.5, 3, 40) + rng.uniform(-6, 2, 40)).astype(np.float32)
+        lbl = feature.rasterize_hits(n, [(0.5 * j, 0.5 * j + 0.07) for j in range(1, 6)])
+        per_video[f"rec{i:02d}.mp4"] = (mbe, lbl, i % 4)
+    paths = feature.build_fold_packs(per_video, str(tmp_path))
+    assert [os.path.basename(p) for p in paths] == [f"mbe_mon_fold{f}.npz" for f in (1, 2, 3, 4)]
+    want = data_ref.build_fold_packs_ref(per_video)
+    folds = data.load_all_npz(str(tmp_path))
+    for f in (1, 2, 3, 4):
+        xtr, ytr, xte, yte = want[f]
+        got = folds[f]
+        assert got["train_x"].dtype == np.float32 and got["train_x"].shape == xtr.shape and got["val_x"].shape == xte.shape
+        np.testing.assert_array_equal(got["train_y"], ytr)
+        np.testing.assert_array_equal(got["val_y"], yte)
+        np.testing.assert_allclose(got["train_x"], xtr, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(got["val_x"], xte, rtol=2e-6, atol=2e-6)
+        assert abs(float(got["train_x"].mean())) < 1e-5 and abs(float(got["train_x"].std()) - 1.0) < 1e-3
