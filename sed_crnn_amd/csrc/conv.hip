@@ -74,6 +74,8 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
         if (!conv_tile(F, T, limit, &p.TT, &p.FT, &p.nft)) return p;
         p.kind = 1; p.nct = nct;
         p.lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
+        const size_t epi = (size_t)(4 * 1024 + 256) * sizeof(float);      // epilogue: four 32x32 transpose scratches + the stat exchange
+        if (p.lds < epi) p.lds = epi;
     }
     if (p.kind < 0) {
         if (Cout % 4 != 0) return p;
@@ -392,9 +394,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         __syncthreads();
     }
 
+    // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
+    // directly is 80 global_store_dword per lane and tile set, 128-byte pieces: store-issue bound, and with both co-resident
+    // workgroups of a CU in lock step nothing hides it (~19 % of the kernel).  Each 32x32 tile is instead transposed through
+    // 4 KB of the (now free) halo buffer: 16 ds_write_b32, then 4 ds_read_b128 give every lane 4 consecutive channels of a
+    // row, and the tile leaves in 4 global_store_dwordx4 per lane (8 full 128-byte rows per instruction).  A 32-float row
+    // stride is conflict-free for both the b32 writes and the b128 lane groups.
     const int co = co0 + ct * 32 + r;
     const float bv = bias ? bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < CV_MTW; ++i) {
         int mt = mp + i * MPARTS;
@@ -404,19 +414,32 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 int row = (j & 3) + 8 * (j >> 2) + 4 * h;
                 int p = mt * 32 + row;
                 int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                float v = acc[i][j] + bv;
+                tsc[row * 32 + r] = v;
                 if (p < MROWS && t0 + tl < T && f < F) {
-                    float v = acc[i][j] + bv;
-                    y[(((size_t)b * T + t0 + tl) * F + f) * Cout + co] = v;
                     s1 += v;
                     s2 += v * v;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int row = rq + 8 * k;
+                int p = mt * 32 + row;
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                if (p < MROWS && t0 + tl < T && f < F)
+                    *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (stat) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        float* red = smem;                          // [4 waves][2][32]; the last loop barrier already passed
+        float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
         if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
         __syncthreads();
         const size_t row = (size_t)b * gridDim.x + blockIdx.x;
