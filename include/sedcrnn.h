@@ -232,7 +232,9 @@ int sed_step_advance(uint64_t* step_state, void* stream);
  * band-major form (any bank whose non-zeros fit the plan: <= 8192 of them, n_mels <= 128).
  *   sed_logmel_tables_bytes  -> size of the blob for this bank (0 = cannot be planned);
  *   sed_logmel_build_tables  -> fills tables_host; the caller copies it to the device once.
- * sed_logmel: mu/inv_sigma (device, may both be NULL) fuse feature.py:127-129's StandardScaler: (x-mu)*inv_sigma. */
+ * sed_logmel: `tables` must be a blob written by sed_logmel_build_tables for this n_mels (the library cannot read device
+ * memory to check it; only its size is validated); mu/inv_sigma (device, may both be NULL) fuse feature.py:127-129's
+ * StandardScaler: (x-mu)*inv_sigma. */
 size_t sed_logmel_tables_bytes(const float* melfb_host, int n_fft, int n_mels);
 int sed_logmel_build_tables(const float* window_host, const float* melfb_host, int n_fft, int n_mels,
                             void* tables_host, size_t tables_bytes);

@@ -141,7 +141,7 @@ template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict__ pcm, long n_samples,
                                                          const uint32_t* __restrict__ tables, int table_words,
                                                          const float* __restrict__ mu, const float* __restrict__ inv_sigma,
-                                                         float* __restrict__ out, long n_frames, int hop, int pad_mode) {
+                                                         float* __restrict__ out, long n_frames, int hop, int pad_mode, int n_mels_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     {   // tables: global -> LDS, once per workgroup (table_words is a multiple of 4)
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
     }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(lds);
-    const int n_mels = (int)hdr[1], iters = (int)hdr[2];
+    // the row length of `out` is the caller's n_mels; a blob built for more bands than that never writes past a row
+    const int n_mels = (int)hdr[1] < n_mels_out ? (int)hdr[1] : n_mels_out, iters = (int)hdr[2];
     const bool two_band = hdr[5] != 0;                       // which mel plan the blob carries (wave-uniform)
     const float2* s_win = reinterpret_cast<const float2*>(lds + LM_OFF_WIN);
     const float2* s_tw = reinterpret_cast<const float2*>(lds + LM_OFF_TW);
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
                 v += part[l.w >> 16];
                 v = logf(v);
                 if (mu) v = (v - mu[m]) * inv_sigma[m];
-                if (live) out[frame * n_mels + m] = v;
+                if (live) out[frame * n_mels_out + m] = v;
             }
         } else {
             // ── list plan: lane r walks entries [r*iters, (r+1)*iters) of the band-major list ──
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
                 for (int j = 0; j < cnt; ++j) v += part[f0 + j];
                 v = logf(v);
                 if (mu) v = (v - mu[m]) * inv_sigma[m];
-                if (live) out[frame * n_mels + m] = v;
+                if (live) out[frame * n_mels_out + m] = v;
             }
         }
     }
@@ -487,7 +488,7 @@ static int launch_logmel(const float* pcm, long n_samples, const void* tables, i
     if (blocks > resident) blocks = resident;
     SedProfScope prof(SED_K_LOGMEL, s, (double)frames * ((double)hop + n_mels) * 4.0);
     logmel_fft_k<WPB><<<(unsigned)blocks, WPB * 64, lds, s>>>(pcm, n_samples, (const uint32_t*)tables, words, mu, inv_sigma,
-                                                              out, frames, hop, pad_mode);
+                                                              out, frames, hop, pad_mode, n_mels);
     SED_LAUNCH_CHECK("logmel");
     return 0;
 }
