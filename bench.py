@@ -185,7 +185,12 @@ def run_rank(args):
     if not plumbing:
         want = int(os.environ.get("WORLD_SIZE", "1"))
         have = torch.cuda.device_count()                     # counting devices does not initialise the GPU
-        if have < want:
+        if args.share_gpu:
+            if backend != "gloo":
+                raise SystemExit("[bench] --share-gpu is a rehearsal of the N-rank path on ONE GPU: it needs --backend gloo "
+                                 "(RCCL does not put two ranks on one device) and its value is not a scaling number")
+            os.environ["LOCAL_RANK"] = "0"
+        elif have < want:
             raise SystemExit(f"[bench] {want} ranks requested but only {have} GPU(s) visible: refusing to share a GPU")
     rank, world, local = init_from_env(backend)
     if world != args.gpus:
@@ -304,7 +309,8 @@ def run_rank(args):
             "config": {"workload": f"BASELINE config 2: mono (B={w['B']},256,40,1) per GPU, 3xConv3x3(128)+BN+ReLU+pool(1,2)+dropout0.5, "
                                    f"BiGRU 2x128, Linear(256,1), BCEWithLogits, Adam lr 1e-3; full fit step (fwd+loss+bwd+allreduce+Adam)",
                        "global_batch": w["B"] * world_seen, "seq_len": w["T"], "n_mels": w["F"],
-                       "parallelism": f"dp{world_seen}" if world_seen > 1 else "single", "final_loss": round(final_loss, 6)},
+                       "parallelism": (f"dp{world_seen}" if world_seen > 1 else "single") + ("-rehearsal-one-gpu" if args.share_gpu else ""),
+                       "final_loss": round(final_loss, 6)},
         })
         out = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                    "scaling", "vs_baseline", "dtype", "data", "config")}
@@ -337,6 +343,8 @@ def main():
     ap.add_argument("--plumbing-only", action="store_true",
                     help="exercise launch + rendezvous + staged all-reduce without the HIP kernels (CPU tests); not a benchmark")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --plumbing-only)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: all ranks on cuda:0 over gloo (the real N-rank code path on a one-GPU box)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("[bench] --gpus must be >= 1")

@@ -181,3 +181,28 @@ def test_rccl_single_rank_staged_allreduce_is_identity():
     res = q.get(timeout=240)
     p.join(30)
     assert res[0] and res[1] and res[2] == res[3] and res[4] == 1.25, res
+
+
+@pytest.mark.timeout(600)
+def test_bench_launches_two_ranks_and_runs_the_staged_step_on_the_hip_path():
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun): the launcher starts two rank processes that run the
+    REAL fit step (HIP kernels, staged all-reduce of the arena between backward stages, max-over-ranks clock).  Only one GPU
+    is available here, so both ranks share cuda:0 over gloo (`--share-gpu`, a rehearsal: the line says so); on a multi-GPU
+    node the same command without those two flags runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 256 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp2-rehearsal-one-gpu"
+    assert out["value"] > 0 and 0.2 < out["config"]["final_loss"] < 1.5
+    assert out["roofline"]["launches"] == 3 * 4            # rank 0's conv forward / data-gradient launches in the timed steps
