@@ -256,6 +256,8 @@ def run_rank(args):
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(w["B"], w["Cin"], w["F"], w["T"], generator=g).to(dev)
     y = (torch.rand(w["B"], w["T"] // 8, 1, generator=g) > 0.8).float().to(dev)
+    if args.conv_bf16x3:
+        model.set_conv_precision("bf16x3")
     step = FusedTrainStep(model, lr=1e-3, loss="bce")
     for _ in range(args.warmup):
         step.step(x, y)
@@ -304,7 +306,7 @@ def run_rank(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not args.conv_bf16x3 else "f32 with conv2/conv3 forward+dgrad on bf16x3-split MFMA (experiment, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: mono (B={w['B']},256,40,1) per GPU, 3xConv3x3(128)+BN+ReLU+pool(1,2)+dropout0.5, "
                                    f"BiGRU 2x128, Linear(256,1), BCEWithLogits, Adam lr 1e-3; full fit step (fwd+loss+bwd+allreduce+Adam)",
@@ -318,9 +320,13 @@ def run_rank(args):
             avg_ms = ms.value / n.value
             tf = units.value / (ms.value * 1e-3) / 1e12
             traffic, rnd = pmc_traffic_bytes()
-            out["roofline"] = {"bound": "mfma", "kernel": DOMINANT_KERNEL + " (conv2/conv3 forward + their data gradients)",
-                               "achieved": round(tf, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            peak = F32_MFMA_PEAK_TFLOPS if not args.conv_bf16x3 else 2500.0 / 3.0      # 3 bf16 MFMA flops per algorithmic flop
+            kname = DOMINANT_KERNEL if not args.conv_bf16x3 else "conv3x3_mfma_fwd_bf16x3_k<4, 2>"
+            if args.conv_bf16x3:
+                traffic = None
+            out["roofline"] = {"bound": "mfma", "kernel": kname + " (conv2/conv3 forward + their data gradients)",
+                               "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(tf / peak, 4), "traffic": traffic,
                                "traffic_note": f"HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this "
                                                f"command (profiles/{rnd}): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
@@ -343,6 +349,9 @@ def main():
     ap.add_argument("--plumbing-only", action="store_true",
                     help="exercise launch + rendezvous + staged all-reduce without the HIP kernels (CPU tests); not a benchmark")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --plumbing-only)")
+    ap.add_argument("--conv-bf16x3", action="store_true",
+                    help="EXPERIMENT, reported on its own line (dtype says so): conv2/conv3 forward + data gradient on the 3-term "
+                         "bf16-split MFMA path instead of exact fp32; the default line stays f32")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks on cuda:0 over gloo (the real N-rank code path on a one-GPU box)")
     args = ap.parse_args()

@@ -63,6 +63,15 @@ int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float*
                     float* y, float* stat_partials,
                     int B, int Cin, int F, int T, int Cout, void* stream);
 
+/* EXPERIMENT, explicit opt-in (never the default, never what bench.py reports as `value`): `mode` 1 runs the MFMA path
+ * (Cin%32 == 0, Cout%32 == 0) on a 3-term bf16 split — x*w ~ x_hi*w_hi + x_hi*w_lo + x_lo*w_hi with fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16: 5.3x the matrix rate of the exact-fp32 MFMA at a relative error of ~4e-6 on a K = 1152 sum
+ * (exact fp32: 3e-7).  mode 0 = the exact fp32 kernels (identical to the entries above).  Weights for mode m must be
+ * packed with sed_conv3x3_pack_weights_ex(..., m); shapes outside the MFMA path fall back to mode 0 in both entries. */
+int sed_conv3x3_pack_weights_ex(const float* w_oihw, float* wp_fwd, float* wp_dgrad, int Cout, int Cin, int mode, void* stream);
+int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y, float* stat_partials,
+                       int B, int Cin, int F, int T, int Cout, int mode, void* stream);
+
 /* Weight gradient (aten::convolution_backward, reached from loss.backward() sed.py:137).
  * dw_oihw[co][ci][kh][kw] = sum_pos x[pos+tap][ci] * dy[pos][co].  dy is channels-last.
  * workspace: sed_conv3x3_wgrad_workspace_bytes(). Deterministic (fixed-order slab reduce). */
@@ -286,6 +295,8 @@ typedef struct sed_net_cfg {
     int n_dense;
     int D[SED_MAX_DENSE];             /* dense sizes; ReLU between layers, last = classes (logits) */
     float bn_eps, bn_momentum;
+    int conv_mode;                    /* 0 = exact fp32 (default); 1 = EXPERIMENT: conv forward / data gradient of the MFMA blocks
+                                         on the 3-term bf16 split (sed_conv3x3_fwd_ex); the weight gradients stay fp32 */
 } sed_net_cfg;
 
 typedef struct sed_net_params {      /* pointers in the reference's own layouts */

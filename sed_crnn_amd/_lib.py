@@ -27,6 +27,7 @@ class NetCfg(C.Structure):
         ("n_gru", C.c_int), ("H", C.c_int * SED_MAX_GRU),
         ("n_dense", C.c_int), ("D", C.c_int * SED_MAX_DENSE),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
+        ("conv_mode", C.c_int),
     ]
 
 
@@ -51,6 +52,8 @@ SIGNATURES = {
     "sed_conv3x3_pack_weights": (_i, [_fp, _fp, _fp, _i, _i, _stream]),
     "sed_conv3x3_stat_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "sed_conv3x3_fwd": (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv3x3_pack_weights_ex": (_i, [_fp, _fp, _fp, _i, _i, _i, _stream]),
+    "sed_conv3x3_fwd_ex": (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_wgrad": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv1_fused_supported": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -122,6 +122,42 @@ extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, in
     return 0;
 }
 
+// ── 3-term bf16-split path (EXPERIMENT, explicit opt-in: mode 1 of the *_ex entries; never the default) ──
+// w = hi + lo with hi = bf16(w), lo = bf16(w - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate): three bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles, i.e. 5.3x the matrix
+// rate; the dropped lo*lo term and the 16-bit split leave a relative error of ~4e-6 on a K = 1152 sum (fp32: 3e-7).
+// Fragment order: [tap][ci/32][(ci%32)/16][co/32][hi|lo][lane = co%32 + 32*((ci%16)/8)][ci%8] bf16 — the B operand of one
+// 32x32x16 MFMA per 1 KiB wave-load; same byte count as the fp32 packing, so it lives in the same workspace region.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t conv_frag_index_b(int tap, int co, int ci, int Cout, int Cin, int part) {
+    int cc = ci >> 5, g = (ci & 31) >> 4, h = (ci & 15) >> 3, j = ci & 7;
+    int cot = co >> 5, r = co & 31;
+    return (((((((size_t)tap * (Cin >> 5) + cc) * 2 + g) * (Cout >> 5) + cot) * 2 + part) * 64) + r + 32 * h) * 8 + j;
+}
+
+__global__ void conv_pack_w_bf16x3_k(const float* __restrict__ w, __bf16* __restrict__ wf, __bf16* __restrict__ wd, int Cout, int Cin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cout * Cin * 9;
+    if (i >= n) return;
+    int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+    if (wf) { wf[conv_frag_index_b(tap, co, ci, Cout, Cin, 0)] = hi; wf[conv_frag_index_b(tap, co, ci, Cout, Cin, 1)] = lo; }
+    if (wd) { wd[conv_frag_index_b(8 - tap, ci, co, Cin, Cout, 0)] = hi; wd[conv_frag_index_b(8 - tap, ci, co, Cin, Cout, 1)] = lo; }
+}
+
+extern "C" int sed_conv3x3_pack_weights_ex(const float* w, float* wf, float* wd, int Cout, int Cin, int mode, void* stream) {
+    if (mode == 0 || Cin % 32 != 0 || Cout % 32 != 0) return sed_conv3x3_pack_weights(w, wf, wd, Cout, Cin, stream);
+    SED_REQUIRE(mode == 1, "conv3x3_pack_weights_ex: unknown mode %d", mode);
+    SED_REQUIRE(w && Cout > 0 && Cin > 0, "conv3x3_pack_weights_ex: bad arguments");
+    int n = Cout * Cin * 9;
+    conv_pack_w_bf16x3_k<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(w, (__bf16*)wf, (__bf16*)wd, Cout, Cin);
+    SED_LAUNCH_CHECK("conv_pack_w_bf16x3");
+    return 0;
+}
+
 // ───────────────────────── small direct forward ─────────────────────────
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
     const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -454,6 +490,193 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     }
 }
 
+template <int NCT, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd_bf16x3_k(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft) {
+    constexpr int MPARTS = 4 / NCT;
+    constexpr int WROWS = 32 * NCT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    // LDS pitch of one halo time-row: F2 rows of CV_LD floats + CV_TPAD.  The pad makes the 16-B slot of flattened
+    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = FT*9 mod 16),
+    // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
+    const int TP = F2 * CV_LD + CV_TPAD;
+    const int HB = (TT + 2) * TP;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tb = blockIdx.x / nft, f0 = (blockIdx.x - tb * nft) * FT;
+    const int b = blockIdx.y, t0 = tb * TT, co0 = blockIdx.z * WROWS;
+    const int ct = wave % NCT, mp = wave / NCT;
+    const int MROWS = TT * FT;
+    const int nMT = (MROWS + 31) >> 5;
+    const int nchunks = Cin / CV_CIC, ncot = Cout >> 5, cot = blockIdx.z * NCT + ct;
+
+    int abase[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int p = (mp + i * MPARTS) * 32 + r;
+        if (p >= MROWS) p = MROWS - 1;
+        int tl = sed_fdiv(p, invF), f = p - tl * FT;
+        abase[i] = tl * TP + f * CV_LD + 4 * h;
+    }
+    f32x16 acc[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    f32x4 ph[CV_NH];
+    int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+#pragma unroll
+    for (int u = 0; u < CV_NH; ++u) {
+        int i = tid + u * 256;
+        int row = i >> 3, tt = sed_fdiv(row, invF2);
+        pdst[u] = (i < HR * 8) ? tt * TP + (row - tt * F2) * CV_LD + (i & 7) * 4 : -1;
+    }
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            int i = tid + u * 256;
+            f32x4 v = {0, 0, 0, 0};
+            if (i < HR * 8) {
+                int row = i >> 3, q = i & 7;
+                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+                int t = t0 + tt - 1, f = f0 + ff - 1;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
+            }
+            ph[u] = v;
+        }
+    };
+    // a position's 32 channels are stored as 32 hi bf16 (64 B) followed by 32 lo bf16 (64 B): the same 128-byte row and
+    // 16-byte slot structure as the fp32 kernel (hi k-group g <-> fp32 group g, lo k-group g <-> fp32 group 2+g), so the
+    // conflict-free pitch analysis carries over
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            if (pdst[u] >= 0) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)ph[u][e]; lo[e] = (__bf16)(ph[u][e] - (float)hi[e]); }
+                const int q = (tid + u * 256) & 7;
+                float* rowp = buf + pdst[u] - 4 * q;
+                *(bf16x4*)(rowp + 2 * q) = hi;
+                *(bf16x4*)(rowp + 16 + 2 * q) = lo;
+            }
+        }
+    };
+    // bq[2g + part]: k-group g (16 channels), part 0 = hi, 1 = lo; one 1 KiB wave-load each
+    const bf16x8* wl = (const bf16x8*)wq + (size_t)cot * 128 + lane;
+    auto load_b = [&](bf16x8* bq, int cc, int tap) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                bq[2 * g + part] = wl[(((size_t)tap * nchunks + cc) * 2 + g) * ncot * 128 + part * 64];
+    };
+
+    fetch(0);
+    commit(smem);
+    bf16x8 bf[4];
+    load_b(bf, 0, 0);
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bool more = cc + 1 < nchunks;
+        if (more) fetch(cc + 1);
+        const float* halo = smem + (cc & 1) * HB;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            bf16x8 bn[4];
+            if (tap < 8) load_b(bn, cc, tap + 1);
+            else if (more) load_b(bn, cc + 1, 0);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = kw * TP + kh * CV_LD;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bf16x8 ah[CV_MTW], al[CV_MTW];
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i) {
+                    ah[i] = *(const bf16x8*)(halo + abase[i] + toff + g * 8);
+                    al[i] = *(const bf16x8*)(halo + abase[i] + toff + 16 + g * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i) {        // tiles past nMT read clamped rows and are never stored
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g + 1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bf[2 * g], acc[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[g] = bn[g];
+        }
+        if (more) commit(smem + ((cc + 1) & 1) * HB);
+        __syncthreads();
+    }
+
+    // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
+    // directly is 80 global_store_dword per lane and tile set, 128-byte pieces: store-issue bound, and with both co-resident
+    // workgroups of a CU in lock step nothing hides it (~19 % of the kernel).  Each 32x32 tile is instead transposed through
+    // 4 KB of the (now free) halo buffer: 16 ds_write_b32, then 4 ds_read_b128 give every lane 4 consecutive channels of a
+    // row, and the tile leaves in 4 global_store_dwordx4 per lane (8 full 128-byte rows per instruction).  A 32-float row
+    // stride is conflict-free for both the b32 writes and the b128 lane groups.
+    const int co = co0 + ct * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int mt = mp + i * MPARTS;
+        if (mt < nMT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                int p = mt * 32 + row;
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                float v = acc[i][j] + bv;
+                tsc[row * 32 + r] = v;
+                if (p < MROWS && t0 + tl < T && f < F) {
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int row = rq + 8 * k;
+                int p = mt * 32 + row;
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                if (p < MROWS && t0 + tl < T && f < F)
+                    *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (stat) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        if (tid < 2 * WROWS) {
+            int which = tid / WROWS, c = tid - which * WROWS;
+            int cti = c >> 5, cr = c & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
 extern "C" int sed_conv3x3_stat_rows(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
     ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
     return p.kind >= 0 ? p.rows : 0;
@@ -470,7 +693,14 @@ static int set_lds(K kernel, size_t bytes) {
 
 extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
                                float* stat, int B, int Cin, int F, int T, int Cout, void* stream) {
+    return sed_conv3x3_fwd_ex(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, 0, stream);
+}
+
+extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
+                                  float* stat, int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
     SED_REQUIRE(x && wp && y, "conv3x3_fwd: null pointer");
+    SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_fwd: unknown mode %d", mode);
+    if (Cin % 32 != 0 || Cout % 32 != 0 || x_is_nchw) mode = 0;      // pack_weights_ex made the same decision
     SED_REQUIRE(B > 0 && Cin > 0 && F > 0 && T > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d Cin=%d F=%d T=%d Cout=%d", B, Cin, F, T, Cout);
     ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
     SED_REQUIRE(p.kind >= 0, "conv3x3_fwd: unsupported shape Cin=%d Cout=%d F=%d (need Cout%%4==0 and a tile that fits LDS)", Cin, Cout, F);
@@ -493,7 +723,18 @@ extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, c
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
         dim3 grid(p.tblocks * p.nft, B, Cout / (32 * p.nct));
-        if (p.nct == 4) {
+        if (mode == 1) {                     // explicit opt-in: 3-term bf16-split MFMA (wp must come from pack_weights_ex(mode 1))
+            if (p.nct == 4) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<4, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            } else if (p.nct == 2) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<2, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            } else {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<1, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            }
+        } else if (p.nct == 4) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
             conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
         } else if (p.nct == 2) {

@@ -40,6 +40,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     SED_REQUIRE(c->n_conv >= 1 && c->n_conv <= SED_MAX_CONV, "net: n_conv=%d out of range", c->n_conv);
     SED_REQUIRE(c->n_gru >= 1 && c->n_gru <= SED_MAX_GRU, "net: n_gru=%d out of range", c->n_gru);
     SED_REQUIRE(c->n_dense >= 1 && c->n_dense <= SED_MAX_DENSE, "net: n_dense=%d out of range", c->n_dense);
+    SED_REQUIRE(c->conv_mode == 0 || c->conv_mode == 1, "net: conv_mode=%d (0 = exact fp32, 1 = bf16x3 experiment)", c->conv_mode);
     memset(L, 0, sizeof(*L));
     L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
     Carver cv;
@@ -186,13 +187,13 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
                     "net_forward: missing parameters of conv block %d", l);
         if (do_a) {
-            SED_TRY(sed_conv3x3_pack_weights(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
-                                             q.C, q.Cin, stream));
+            SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
+                                                q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
             if (q.fused) {
                 if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C, stream));
             } else {
-                SED_TRY(sed_conv3x3_fwd(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
-                                        training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, stream));
+                SED_TRY(sed_conv3x3_fwd_ex(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
+                                           training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
             }
             if (training && !one_shot) SED_TRY(sed_bn_stat_sums(ws + L.stat[l], q.rows, q.C, ws + L.bn_sums[l], stream));
         }
@@ -438,7 +439,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             continue;
         }
         // data gradient = the same convolution with flipped, transposed taps
-        SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+        SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
         if (l > 1) {
             SED_TRY(bn_passes(l - 1, stream));
             continue;
@@ -488,7 +489,7 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
         SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
                                   B, q.Cin, q.F, q.T, q.C, stream));
         if (l > 0)
-            SED_TRY(sed_conv3x3_fwd(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, stream));
+            SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
     }
     return 0;
 }

@@ -317,7 +317,15 @@ class HipCRNN(nn.Module):
         for j, d in enumerate(self.dense):
             c.D[j] = d
         c.bn_eps, c.bn_momentum = self.bn_eps, self.bn_momentum
+        c.conv_mode = int(getattr(self, "conv_mode", 0))
         return c
+
+    def set_conv_precision(self, name="f32"):
+        """EXPERIMENT, explicit opt-in: ``"bf16x3"`` runs the forward and the data gradient of the 128-channel conv blocks on
+        a 3-term bf16 split (fp32 accumulate; relative error ~4e-6 per K = 1152 sum instead of 3e-7); ``"f32"`` (default) is
+        the exact-fp32 MFMA path that every parity claim and the bench refer to."""
+        self.conv_mode = {"f32": 0, "bf16x3": 1}[name]
+        return self
 
     def _param_structs(self):
         if self._structs is None:

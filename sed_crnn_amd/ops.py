@@ -16,15 +16,15 @@ def _f32c(t):
     return t
 
 
-def conv3x3_pack(w):
+def conv3x3_pack(w, mode=0):
     Cout, Cin = w.shape[:2]
     wf = torch.empty(9, Cout, Cin, device=w.device)
     wd = torch.empty(9, Cin, Cout, device=w.device)
-    check(lib().sed_conv3x3_pack_weights(ptr(_f32c(w)), ptr(wf), ptr(wd), Cout, Cin, stream_ptr()), "conv3x3_pack")
+    check(lib().sed_conv3x3_pack_weights_ex(ptr(_f32c(w)), ptr(wf), ptr(wd), Cout, Cin, mode, stream_ptr()), "conv3x3_pack")
     return wf, wd
 
 
-def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True):
+def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True, mode=0):
     """x: [B,Cin,F,T] if x_is_nchw else [B,T,F,Cin]; wp [9,Cout,Cin] -> y [B,T,F,Cout] (+ stat partials)."""
     if x_is_nchw:
         B, Cin, F, T = x.shape
@@ -36,8 +36,8 @@ def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True):
     if want_stats:
         rows = lib().sed_conv3x3_stat_rows(B, Cin, F, T, Cout, int(x_is_nchw))
         stat = torch.zeros(max(rows, 1), 2, Cout, device=x.device)
-    check(lib().sed_conv3x3_fwd(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(wp)), ptr(bias), ptr(y), ptr(stat),
-                                B, Cin, F, T, Cout, stream_ptr()), "conv3x3_fwd")
+    check(lib().sed_conv3x3_fwd_ex(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(wp)), ptr(bias), ptr(y), ptr(stat),
+                                   B, Cin, F, T, Cout, mode, stream_ptr()), "conv3x3_fwd")
     return y, stat
 
 

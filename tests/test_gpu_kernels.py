@@ -374,3 +374,33 @@ def test_logmel_edges_odd_hop_custom_bank_and_shift_invariance(ops):
     a = feature.mbe(y)
     b = feature.mbe(y[1024:].contiguous())
     assert torch.equal(a[3:1990], b[2:1989])
+
+
+@pytest.mark.parametrize("B,Cin,Fm,T,Cout", [(2, 128, 40, 16, 128), (1, 32, 8, 8, 64), (3, 64, 40, 6, 32), (2, 128, 128, 8, 128)])
+def test_conv3x3_bf16x3_experiment_forward_and_dgrad(ops, B, Cin, Fm, T, Cout):
+    """the opt-in 3-term bf16-split MFMA path (mode 1): forward, statistics partials and the data gradient (same kernel,
+    flipped/transposed weights) against torch fp32 on CPU.  Its error model is ~4e-6 relative to the magnitude of the
+    K = 9*Cin sum (exact-fp32 path: 3e-7); the tolerance below is 20x tighter than what one bf16 term alone would give."""
+    torch.manual_seed(B * 7 + Cin)
+    x = torch.randn(B, T, Fm, Cin)
+    w = torch.randn(Cout, Cin, 3, 3) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(Cout)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 2, 1), w, bias, padding=1).permute(0, 3, 2, 1).contiguous()   # [B,T,F,Cout]
+    wf, wd = ops.conv3x3_pack(w.cuda(), mode=1)
+    y, stat = ops.conv3x3_fwd(x.cuda(), wf, bias.cuda(), False, mode=1)
+    scale = float(ref.abs().mean())
+    err = (y.cpu() - ref).abs()
+    assert float(err.max()) < 1e-4 * scale * 10 and float(err.mean()) < 2e-5 * scale, (float(err.max()), float(err.mean()), scale)
+    s = stat.sum(0).cpu()
+    torch.testing.assert_close(s[0], ref.sum((0, 1, 2)), rtol=1e-3, atol=2e-2)
+    torch.testing.assert_close(s[1], (ref * ref).sum((0, 1, 2)), rtol=1e-3, atol=2e-2)
+    dy = torch.randn(B, T, Fm, Cout)
+    dref = torch.nn.grad.conv2d_input((B, Cin, Fm, T), w, dy.permute(0, 3, 2, 1).contiguous(), padding=1).permute(0, 3, 2, 1)
+    dx, _ = ops.conv3x3_fwd(dy.cuda(), wd, None, False, want_stats=False, mode=1)
+    derr = (dx.cpu() - dref).abs()
+    dscale = float(dref.abs().mean())
+    assert float(derr.max()) < 1e-3 * dscale and float(derr.mean()) < 2e-5 * dscale, (float(derr.max()), float(derr.mean()), dscale)
+    # and the exact-fp32 path on the same inputs is an order of magnitude closer
+    wf0, _ = ops.conv3x3_pack(w.cuda())
+    y0, _ = ops.conv3x3_fwd(x.cuda(), wf0, bias.cuda(), False)
+    assert float((y0.cpu() - ref).abs().mean()) < 0.3 * float(err.mean()) + 1e-9

@@ -734,3 +734,32 @@ def test_single_step_gradients_are_as_close_to_float64_as_torch_float32(sed):
         worst = max(worst, e_h / (e_t + 1e-30))
         assert e_h <= 3.0 * e_t + 2e-6, (k, e_h, e_t)
     print(f"single-step gradient error vs float64: worst HIP/torch-f32 ratio over the parameters = {worst:.2f}")
+
+
+def test_bf16x3_conv_experiment_stays_within_the_parity_tolerances(sed):
+    """model.set_conv_precision("bf16x3") (explicit opt-in, not the default): the full-width golden g5 (K = 1152) and a
+    C = 128 oracle comparison with the SAME tolerances as the exact-fp32 path; and the default is unchanged."""
+    from oracle import crnn_ref
+    d = load_golden("g5_sed_c128.npz")
+    ref = crnn_ref.SedNetRef(conv_channels=128, dropout=0.0)
+    m = sed.TimePooledCRNN(conv_channels=128, dropout=0.0)
+    assert m._cfg(1, 8).conv_mode == 0                                 # exact fp32 unless asked
+    m.load_state_dict(crnn_ref.rs_state_dict(ref, seed=int(d["weight_seed"])))
+    m.cuda().set_conv_precision("bf16x3")
+    assert m._cfg(1, 8).conv_mode == 1
+    x, y = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["y"]).cuda()
+    m.eval()
+    _cmp(m(x), d["logits_eval"], atol=2e-4)
+    m.train()
+    out = m(x)
+    sed.BCEWithLogitsLoss()(out, y).backward()
+    _cmp(out, d["logits_train"], atol=2e-4)
+    named = dict(m.named_parameters())
+    for k in d:
+        if k.startswith("grad.") and k[5:] in named:
+            _cmp(named[k[5:]].grad, d[k], atol=5e-5, rtol=5e-3, msg=k)
+    torch.manual_seed(7)
+    ref2 = crnn_ref.SedNetRef(conv_channels=128, dropout=0.0, in_channels=2, n_mels=40, gru_hidden=128)
+    m2 = sed.TimePooledCRNN(conv_channels=128, dropout=0.0, in_channels=2, n_mels=40, gru_hidden=128).set_conv_precision("bf16x3")
+    x2, y2 = crnn_ref.synthetic_batch(3, 2, 40, 32, 4, seed=5)
+    _oracle_vs_hip(sed, ref2, m2, x2, y2)

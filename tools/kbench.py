@@ -39,6 +39,9 @@ def main():
             ms = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, False), a.iters)
             fl = 2 * 9 * 128 * 128 * B * T * 40
             print(f"conv3x3_mfma_fwd  B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+            wfb, _ = ops.conv3x3_pack(w, mode=1)
+            ms = timeit(lambda: ops.conv3x3_fwd(x, wfb, bias, False, mode=1), a.iters)
+            print(f"conv3x3 bf16x3 (experiment)  B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} fp32-equivalent TFLOP/s")
     if a.what in ("wgrad", "all"):
         for T in (128, 64):
             x = torch.randn(B, T, 40, 128, device=dev)
