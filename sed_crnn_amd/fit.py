@@ -40,6 +40,8 @@ class EpochTally:
 
     def tensors(self):
         """(probabilities, labels) of the whole epoch, windows concatenated in visiting order, on the device"""
+        if not self.probs:
+            raise ValueError("the loader produced no batch (fewer windows than one batch with drop_last?)")
         return torch.cat(self.probs), torch.cat(self.labels)
 
     def counts(self, frames_in_1_sec=FPS_OUT, threshold=0.5):

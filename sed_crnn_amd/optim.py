@@ -54,6 +54,21 @@ class FusedAdam(torch.optim.Optimizer):
             self.state[q]["v"] = self._arena[3][o:o + n].view(q.shape)
         return self
 
+    def load_state_dict(self, state_dict):
+        """torch replaces the per-parameter state tensors by fresh ones: copy them back into the one moment store of the
+        attached arena and re-view them, so the single-launch path keeps seeing the loaded moments"""
+        super().load_state_dict(state_dict)
+        if self._arena is not None:
+            m = self._arena_model
+            for q, o in zip(m._arena_params, m._arena_offsets):
+                n = q.numel()
+                st = self.state.get(q, {})
+                for key, store in (("m", self._arena[2]), ("v", self._arena[3])):
+                    view = store[o:o + n].view(q.shape)
+                    if key in st and st[key].data_ptr() != view.data_ptr():
+                        view.copy_(st[key])
+                    self.state[q][key] = view
+
     def zero_grad(self, set_to_none=True):
         if self._arena_model is not None:
             self._arena_model._arena_dirty = False

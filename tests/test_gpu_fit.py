@@ -245,6 +245,14 @@ def test_fused_adam_attaches_itself_and_matches_torch_adam_over_several_steps(se
     for k, v in m.state_dict().items():
         if v.dtype.is_floating_point and not (k.startswith("convs.") and k.endswith(".bias")):       # zero-gradient coordinates aside
             np.testing.assert_allclose(v.cpu().numpy(), sd_r[k].numpy(), atol=3e-4, rtol=2e-2, err_msg=k)
+    # optimiser checkpoints: the loaded moments land in the arena's one store (the single-launch path must see them)
+    sd = opt.state_dict()
+    opt2 = sed.FusedAdam(m.parameters(), lr=2e-3, weight_decay=1e-4, max_grad_norm=1.0)
+    assert float(opt2._arena[2].abs().sum()) == 0.0
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2._arena[2], opt._arena[2]) and torch.equal(opt2._arena[3], opt._arena[3])
+    assert opt2.state[m.fc.weight]["m"].data_ptr() == opt2._arena[2][m._arena_offsets[0]:].data_ptr()
+    assert opt2.param_groups[0]["step"] == opt.param_groups[0]["step"] == 6
     # moving the model after the optimiser exists is an error, not silent garbage
     m.cpu()
     with pytest.raises(RuntimeError, match="rebuilt"):
