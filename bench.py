@@ -306,7 +306,7 @@ def run_rank(args):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if not args.conv_bf16x3 else "f32 with conv2/conv3 forward+dgrad on bf16x3-split MFMA (experiment, not the headline)",
+            "dtype": "f32" if not args.conv_bf16x3 else "f32 with conv2/conv3 forward+dgrad+wgrad on bf16x3-split MFMA (experiment, not the headline)",
             "data": "synthetic",
             "config": {"workload": f"BASELINE config 2: mono (B={w['B']},256,40,1) per GPU, 3xConv3x3(128)+BN+ReLU+pool(1,2)+dropout0.5, "
                                    f"BiGRU 2x128, Linear(256,1), BCEWithLogits, Adam lr 1e-3; full fit step (fwd+loss+bwd+allreduce+Adam)",
@@ -350,7 +350,7 @@ def main():
                     help="exercise launch + rendezvous + staged all-reduce without the HIP kernels (CPU tests); not a benchmark")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo with --plumbing-only)")
     ap.add_argument("--conv-bf16x3", action="store_true",
-                    help="EXPERIMENT, reported on its own line (dtype says so): conv2/conv3 forward + data gradient on the 3-term "
+                    help="EXPERIMENT, reported on its own line (dtype says so): conv2/conv3 forward, data and weight gradient on the 3-term "
                          "bf16-split MFMA path instead of exact fp32; the default line stays f32")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks on cuda:0 over gloo (the real N-rank code path on a one-GPU box)")

@@ -79,6 +79,10 @@ size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout)
 int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                       void* workspace, int B, int Cin, int F, int T, int Cout, void* stream);
 
+/* mode 1 (EXPERIMENT, as sed_conv3x3_fwd_ex): the MFMA path on the 3-term bf16 split; other shapes run mode 0. */
+int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
+                         void* workspace, int B, int Cin, int F, int T, int Cout, int mode, void* stream);
+
 /* ───────────── BatchNorm2d + ReLU + MaxPool2d + Dropout (sed.py:89-92,107; crnn_lightning.py:48-52) ─────────────
  * Training statistics: reduce the conv partials in a fixed order (double accumulation),
  * write mean/rstd and the fused scale/shift (scale = gamma*rstd, shift = beta - mean*scale),
@@ -295,8 +299,8 @@ typedef struct sed_net_cfg {
     int n_dense;
     int D[SED_MAX_DENSE];             /* dense sizes; ReLU between layers, last = classes (logits) */
     float bn_eps, bn_momentum;
-    int conv_mode;                    /* 0 = exact fp32 (default); 1 = EXPERIMENT: conv forward / data gradient of the MFMA blocks
-                                         on the 3-term bf16 split (sed_conv3x3_fwd_ex); the weight gradients stay fp32 */
+    int conv_mode;                    /* 0 = exact fp32 (default); 1 = EXPERIMENT: conv forward, data gradient and weight gradient of the
+                                         MFMA blocks on the 3-term bf16 split (sed_conv3x3_fwd_ex / sed_conv3x3_wgrad_ex) */
 } sed_net_cfg;
 
 typedef struct sed_net_params {      /* pointers in the reference's own layouts */

@@ -757,7 +757,14 @@ struct WgradPlan {
     size_t lds, slab_floats;
 };
 
-static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+// bytes of the two-buffer bf16 hi/lo LDS image of conv3x3_wgrad_bf16x3_k (x pitch 64 B, dy pitch 320 B, 16-position k-steps)
+static size_t wgrad_bf16x3_lds(int TT, int FT) {
+    const size_t HR = (size_t)(TT + 2) * (FT + 2), MPAD = (size_t)((TT * FT + 15) / 16) * 16;
+    if (HR * 8 > 256 * 8 || MPAD * 32 > 256 * 14) return (size_t)1 << 30;      // the loader's item budget (WB_NX / WB_ND)
+    return 2 * (HR * 128 + MPAD * 640);
+}
+
+static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode = 0) {
     WgradPlan p{};
     p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
     p.FT = F; p.nft = 1;
@@ -772,6 +779,11 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
                (p.TT + 4) * (p.FT + 2) * 8 <= 256 * WG_NX)
             p.TT += 2;
         p.lds = (size_t)2 * ((size_t)(p.TT + 2) * (p.FT + 2) * 32 + (size_t)p.TT * p.FT * 128) * sizeof(float);
+        if (mode == 1) {           // the padded dy pitch makes the image larger than the fp32 one: fewer time rows per tile
+            p.TT = 1;
+            while (p.TT + 1 <= 62 && p.TT + 1 <= T && wgrad_bf16x3_lds(p.TT + 1, p.FT) <= 160 * 1024) p.TT += 1;
+            p.lds = wgrad_bf16x3_lds(p.TT, p.FT);
+        }
     } else {
         p.TT = 4;
         if (p.TT > T) p.TT = T;
@@ -1067,6 +1079,169 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
         }
 }
 
+// ── weight gradient on the 3-term bf16 split (EXPERIMENT, mode 1 of sed_conv3x3_wgrad_ex) ──
+// dW[tap][ci][co] = sum_pos x[pos+tap][ci] dy[pos][co]: the contraction index is the POSITION, while both operands are
+// stored position-major (channels contiguous), so the k-contiguous fragments of v_mfma_f32_32x32x16_bf16 are gathered with
+// ds_read_b64_tr_b16: per 16-lane group a 4-position x 16-channel block comes back transposed (lane = channel, element =
+// position); two reads give a lane its 8 k values.  LDS image per tile: x halo [position][32 ci] bf16, hi and lo arrays with
+// a 64-byte pitch, dy [position][128 co] bf16, hi and lo arrays with a 320-byte pitch (both conflict-free for the
+// transposed reads: the 8 row/group chunks of a 32-lane half land on the 8 distinct 32-byte slots of the bank period).
+// Eight waves: 0-3 compute (wave w: co 32w..32w+31, nine tap accumulators), 4-7 load the next tile (global fp32 ->
+// hi/lo split -> LDS) while the others run the MFMA loop.  Same tiles, slabs and fixed-order slab reduction as the fp32 kernel.
+typedef __attribute__((address_space(3))) bf16x4* sed_lds_bf16x4_t;
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((sed_lds_bf16x4_t)(p0));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((sed_lds_bf16x4_t)(p1));
+    return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+#define WB_DYP 160      // dy row pitch in bf16 (320 B)
+#define WB_NX 8         // loader items (float4) per lane of the halo tile:  HR*8    <= 256*WB_NX
+#define WB_ND 14        // loader items (float4) per lane of the dY tile:    MPAD*32 <= 256*WB_ND
+template <bool MT>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    const int MROWS = TT * FT;
+    const int KS = (MROWS + 15) >> 4, MPAD = KS * 16;
+    // per buffer (bf16 units): x hi [HR][32], x lo [HR][32], dy hi [MPAD][160], dy lo [MPAD][160]
+    const int XP = HR * 32, DP = MPAD * WB_DYP, BUFH = 2 * XP + 2 * DP;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
+    __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+    if (wave >= 4) {
+        // ── loaders: global fp32 -> registers (one tile ahead of the LDS image, two ahead of the MFMA loop) -> (hi, lo)
+        // bf16 -> LDS.  All loads of a tile are issued back to back and only waited for one tile later. ──
+        constexpr int NX = WB_NX, ND = WB_ND;
+        const int lt = tid - 256;
+        int xo[NX], xt[NX], dofs[ND], dt[ND];            // tile-invariant item coordinates, as in the fp32 kernel
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            int i = lt + u * 256, row = i >> 3, qq = i & 7;
+            int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+            xt[u] = (i < HR * 8) ? (tt | (ff << 8)) : (1 << 24);
+            xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + qq * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            int i = lt + u * 256, row = i >> 5, qq = i & 31;
+            int tl = sed_fdiv(row, invF), fl = row - tl * FT;
+            dt[u] = (row < MROWS) ? (tl | (fl << 8)) : (1 << 24);
+            dofs[u] = (tl * F + fl) * Cout + co0 + qq * 4;
+        }
+        f32x4 rx[NX], rd[ND];
+        auto fetch = [&](int tile) {
+            int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
+            int tb = rem / nft, f0 = MT ? (rem - tb * nft) * FT : 0, t0 = tb * TT;
+            const float* xb = x + (((size_t)b * T + t0) * F + f0) * Cin;
+            const float* db = dy + (((size_t)b * T + t0) * F + f0) * Cout;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int t = t0 + (xt[u] & 255) - 1, f = f0 + (xt[u] >> 8) - 1;
+                rx[u] = (f32x4){0, 0, 0, 0};
+                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F) rx[u] = *(const f32x4*)(xb + xo[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                rd[u] = (f32x4){0, 0, 0, 0};
+                if (t0 + (dt[u] & 255) < T && f0 + (dt[u] >> 8) < F) rd[u] = *(const f32x4*)(db + dofs[u]);
+            }
+        };
+        auto split_store = [&](const f32x4 v, __bf16* hi_at, __bf16* lo_at) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+            *(bf16x4*)hi_at = hi;
+            *(bf16x4*)lo_at = lo;
+        };
+        auto commit = [&](__bf16* buf) {
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int i = lt + u * 256;
+                if (i < HR * 8) split_store(rx[u], buf + i * 4, buf + XP + i * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int i = lt + u * 256, at = (i >> 5) * WB_DYP + (i & 31) * 4;
+                if (i < MPAD * 32) split_store(rd[u], buf + 2 * XP + at, buf + 2 * XP + DP + at);
+            }
+        };
+        int tile = blockIdx.x, cur = 0;
+        if (tile < ntiles) { fetch(tile); commit(lds); }
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        __syncthreads();
+        for (; tile < ntiles; tile += gridDim.x) {
+            const int nxt = tile + gridDim.x, nn = nxt + gridDim.x;
+            if (nxt < ntiles) commit(lds + (cur ^ 1) * BUFH);       // that buffer was last read before the previous barrier
+            if (nn < ntiles) fetch(nn);                             // in flight across the barrier (plain loads: no vmcnt drain)
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    // transposed-read lane roles: 16-lane group G = lane >> 4 covers channels 16*(G&1)..+15 and k half h = G >> 1;
+    // lane 4q+p of a group addresses block row q (a position), channels 4p..4p+3
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int h = G >> 1, cb = 16 * (G & 1) + 4 * pp;
+    auto compute = [&](const __bf16* buf) {
+        const __bf16* xh = buf;
+        const __bf16* xl = buf + XP;
+        const __bf16* dh = buf + 2 * XP + wave * 32 + cb;
+        const __bf16* dl = dh + DP;
+        for (int ks = 0; ks < KS; ++ks) {
+            // the two positions this lane addresses in this k-step (t = 0, 1): m = ks*16 + 8h + 4t + q
+            int m0 = ks * 16 + 8 * h + q, m1 = m0 + 4;
+            const bf16x8 bhi = lds_tr8(dh + m0 * WB_DYP, dh + m1 * WB_DYP);
+            const bf16x8 blo = lds_tr8(dl + m0 * WB_DYP, dl + m1 * WB_DYP);
+            if (m0 >= MROWS) m0 = MROWS - 1;                  // padded positions carry dy = 0; keep the x address in range
+            if (m1 >= MROWS) m1 = MROWS - 1;
+            const int tl0 = sed_fdiv(m0, invF), tl1 = sed_fdiv(m1, invF);
+            const int hp0 = (tl0 * F2 + (m0 - tl0 * FT)) * 32 + cb, hp1 = (tl1 * F2 + (m1 - tl1 * FT)) * 32 + cb;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int sh = (kw * F2 + kh) * 32;
+                    const bf16x8 ahi = lds_tr8(xh + hp0 + sh, xh + hp1 + sh);
+                    const bf16x8 alo = lds_tr8(xl + hp0 + sh, xl + hp1 + sh);
+                    const int k = kh * 3 + kw;
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[k], 0, 0, 0);
+                }
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    __syncthreads();                                     // the first tile has landed
+    for (; tile < ntiles; tile += gridDim.x) {
+        compute(lds + cur * BUFH);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
+            sl[((size_t)k * Cin + ci0 + row) * Cout + co0 + wave * 32 + r] = acc[k][j];
+        }
+}
+
 // mfma reduce: dw[co][ci][tap] = sum_g slabs[g][tap][ci][co]
 __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float* __restrict__ dw,
                                          int ngroups, int Cin, int Cout) {
@@ -1082,16 +1257,35 @@ __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float*
 
 extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
                                  int B, int Cin, int F, int T, int Cout, void* stream) {
+    return sed_conv3x3_wgrad_ex(x, x_is_nchw, dy, dw, workspace, B, Cin, F, T, Cout, 0, stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                                    int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
     SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
+    SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_wgrad: unknown mode %d", mode);
     SED_REQUIRE(Cout % 4 == 0, "conv3x3_wgrad: Cout must be a multiple of 4 (got %d)", Cout);
-    WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw);
+    WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
     hipStream_t s = as_stream(stream);
     float* slabs = (float*)workspace;
     int n = Cin * 9 * Cout;
     const double npos = (double)B * T * F;
     SedProfScope prof(p.kind == 1 ? SED_K_CONV_MFMA_WGRAD : SED_K_CONV_SMALL_WGRAD, s,
                       p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
-    if (p.kind == 1) {
+    if (p.kind == 1 && mode == 1) {
+        dim3 grid(p.ngroups, Cin / 32, Cout / 128);
+        const size_t lds = p.lds;
+        SED_REQUIRE(lds <= 160 * 1024, "conv3x3_wgrad (bf16x3): tile %dx%d needs %zu B of LDS", p.TT, p.FT, lds);
+        if (p.nft == 1) {
+            SED_TRY(set_lds(conv3x3_wgrad_bf16x3_k<false>, lds));
+            conv3x3_wgrad_bf16x3_k<false><<<grid, 512, lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_wgrad_bf16x3_k<true>, lds));
+            conv3x3_wgrad_bf16x3_k<true><<<grid, 512, lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        }
+        SED_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
+        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    } else if (p.kind == 1) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
         if (p.nft == 1) {
             SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));

@@ -418,7 +418,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         const ConvL& q = L.cv[l];
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         float* scratch = ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws);
-        return sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, st);
+        return sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, st);
     };
     auto wgrad = [&](int l) -> int { return wgrad_on(l, stream); };
     // an unfused first block (Cin > 2): its HBM-bound weight gradient follows its BatchNorm backward on the same stream, so with
@@ -486,8 +486,8 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
         SED_TRY(bn_backward(L, c, p, g, x, ws, seed, nullptr, l, 2, count_scale, stream));
         if (q.fused) continue;
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
-        SED_TRY(sed_conv3x3_wgrad(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
-                                  B, q.Cin, q.F, q.T, q.C, stream));
+        SED_TRY(sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
+                                     B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
         if (l > 0)
             SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
     }

@@ -41,7 +41,7 @@ def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True, mode=0):
     return y, stat
 
 
-def conv3x3_wgrad(x, dy, x_is_nchw):
+def conv3x3_wgrad(x, dy, x_is_nchw, mode=0):
     if x_is_nchw:
         B, Cin, F, T = x.shape
     else:
@@ -50,8 +50,8 @@ def conv3x3_wgrad(x, dy, x_is_nchw):
     nbytes = lib().sed_conv3x3_wgrad_workspace_bytes(B, Cin, F, T, Cout)
     ws = torch.empty(nbytes // 4 + 1, device=x.device)
     dw = torch.empty(Cout, Cin, 3, 3, device=x.device)
-    check(lib().sed_conv3x3_wgrad(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(dy)), ptr(dw), ptr(ws),
-                                  B, Cin, F, T, Cout, stream_ptr()), "conv3x3_wgrad")
+    check(lib().sed_conv3x3_wgrad_ex(ptr(_f32c(x)), int(x_is_nchw), ptr(_f32c(dy)), ptr(dw), ptr(ws),
+                                     B, Cin, F, T, Cout, mode, stream_ptr()), "conv3x3_wgrad")
     return dw
 
 

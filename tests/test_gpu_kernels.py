@@ -404,3 +404,23 @@ def test_conv3x3_bf16x3_experiment_forward_and_dgrad(ops, B, Cin, Fm, T, Cout):
     wf0, _ = ops.conv3x3_pack(w.cuda())
     y0, _ = ops.conv3x3_fwd(x.cuda(), wf0, bias.cuda(), False)
     assert float((y0.cpu() - ref).abs().mean()) < 0.3 * float(err.mean()) + 1e-9
+
+
+@pytest.mark.parametrize("B,Cin,Fm,T,Cout", [(2, 128, 40, 16, 128), (1, 32, 8, 8, 128), (3, 64, 20, 7, 128), (2, 32, 10, 33, 256),
+                                             (2, 128, 46, 5, 128), (1, 32, 5, 3, 128)])
+def test_conv3x3_bf16x3_experiment_weight_gradient(ops, B, Cin, Fm, T, Cout):
+    """the opt-in weight gradient on the 3-term bf16 split (mode 1 of sed_conv3x3_wgrad_ex; positions gathered into the
+    MFMA k index with transposed LDS reads) against torch in float64: odd mel widths and time lengths exercise the padded
+    k-steps and the clamped halo addresses; the sum runs over B*T*F positions, so the error is measured against the
+    magnitude of that sum like the forward's."""
+    torch.manual_seed(B * 11 + Cin + T)
+    x = torch.randn(B, T, Fm, Cin)
+    dy = torch.randn(B, T, Fm, Cout)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 2, 1).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 2, 1).double(), padding=1)
+    dw = ops.conv3x3_wgrad(x.cuda(), dy.cuda(), False, mode=1).cpu()
+    dw0 = ops.conv3x3_wgrad(x.cuda(), dy.cuda(), False).cpu()
+    scale = float(ref.abs().mean())
+    err, err0 = (dw.double() - ref).abs(), (dw0.double() - ref).abs()
+    assert float(err.max()) < 2e-4 * scale and float(err.mean()) < 2e-5 * scale, (float(err.max()), float(err.mean()), scale)
+    assert float(err0.mean()) < float(err.mean())                       # the exact path stays the closer one
+    assert torch.equal(dw, ops.conv3x3_wgrad(x.cuda(), dy.cuda(), False, mode=1).cpu())      # fixed-order reduction: run to run identical

@@ -49,6 +49,8 @@ def main():
             ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, False), a.iters)
             fl = 2 * 9 * 128 * 128 * B * T * 40
             print(f"conv3x3_mfma_wgrad B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+            ms = timeit(lambda: ops.conv3x3_wgrad(x, dy, False, mode=1), a.iters)
+            print(f"conv3x3 wgrad bf16x3 (experiment) B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} fp32-equivalent TFLOP/s")
     if a.what in ("gemm", "all"):
         M, K, H = 4096, 5120, 128
         X = torch.randn(M, K, device=dev)
