@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_fwd_tcf_k(
 static int check_pool(const char* who, int B, int T, int F, int C, int pf, int pt) {
     SED_REQUIRE(B > 0 && T > 0 && F > 0 && C > 0 && pf > 0 && pt > 0, "%s: bad shape", who);
     SED_REQUIRE(C % 4 == 0, "%s: C must be a multiple of 4 (got %d)", who, C);
-    SED_REQUIRE(T % pt == 0 && F % pf == 0, "%s: T=%d / F=%d must be divisible by the pool (%d,%d)", who, T, F, pt, pf);
+    // like nn.MaxPool2d (ceil_mode=False; sed.py:90) a ragged tail is dropped: T' = floor(T/pt), F' = floor(F/pf); the tail
+    // still takes part in the batch statistics and, in the backward, receives their gradient terms
+    SED_REQUIRE(T / pt >= 1 && F / pf >= 1, "%s: T=%d / F=%d smaller than the pool (%d,%d)", who, T, F, pt, pf);
     return 0;
 }
 
@@ -409,6 +411,22 @@ __global__ __launch_bounds__(256) void bn_relu_pool_drop_bwd_k(
                         a1 += o;
                     }
             }
+        }
+        if (MODE == 1) {
+            // positions no pooling window covers (floor pooling): no gradient arrives from above, the statistics terms remain
+            auto tail = [&](int t, int f) {
+                const size_t off = (((b * T + t) * F + f) * (size_t)C) + c4 * 4;
+                const f32x4 v = *(const f32x4*)(y + off);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = sc[k] * (-sg[k] - (v[k] - mu[k]) * rs[k] * sgx[k]);
+                *(f32x4*)(dy + off) = o;
+                a1 += o;
+            };
+            const int ftail = F - Fp * pf, ttail = T - Tp * pt;
+            for (int i = slot; i < pt * ftail; i += nslots) tail(tp * pt + i / ftail, Fp * pf + i % ftail);
+            if (tp == Tp - 1)
+                for (int i = slot; i < ttail * F; i += nslots) tail(Tp * pt + i / F, i % F);
         }
     }
     // block reduction of the per-thread partial sums, fixed slot order

@@ -52,8 +52,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         q.Cin = Cin; q.C = c->C[l]; q.T = T; q.F = F; q.pf = c->pool_f[l]; q.pt = c->pool_t[l];
         q.drop = c->drop_p[l]; q.nchw = (l == 0);
         SED_REQUIRE(q.C > 0 && q.C % 4 == 0, "net: conv channels C[%d]=%d must be a positive multiple of 4", l, q.C);
-        SED_REQUIRE(q.pf >= 1 && q.pt >= 1 && T % q.pt == 0 && F % q.pf == 0,
-                    "net: block %d: T=%d/F=%d not divisible by pool (%d,%d)", l, T, F, q.pt, q.pf);
+        SED_REQUIRE(q.pf >= 1 && q.pt >= 1 && T / q.pt >= 1 && F / q.pf >= 1,       // floor pooling, like nn.MaxPool2d
+                    "net: block %d: T=%d/F=%d smaller than the pool (%d,%d)", l, T, F, q.pt, q.pf);
         SED_REQUIRE(q.drop >= 0.f && q.drop < 1.f, "net: drop_p[%d]=%f out of [0,1)", l, q.drop);
         q.Tp = T / q.pt; q.Fp = F / q.pf;
         // block 1 with <= 2 input channels: the conv output is recomputed in every pass and never stored (conv1.hip)

@@ -384,8 +384,8 @@ class HipCRNN(nn.Module):
             raise _lib.SedHipError("sed_crnn_amd: move the module to the GPU first (model.to('cuda'))")
         if x.dim() != 4 or x.shape[1] != self.in_channels or x.shape[2] != self.n_mels:
             raise ValueError(f"expected input [B,{self.in_channels},{self.n_mels},T], got {tuple(x.shape)}")
-        if x.shape[3] % self.time_factor:
-            raise ValueError(f"T={x.shape[3]} must be a multiple of {self.time_factor}")
+        if x.shape[3] < self.time_factor:        # floor pooling like nn.MaxPool2d (sed.py:90): a ragged tail is dropped
+            raise ValueError(f"T={x.shape[3]} is shorter than one output frame ({self.time_factor} input frames)")
         if not (x.dtype.is_floating_point or x.dtype in (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64)):
             raise ValueError(f"unsupported input dtype {x.dtype}")
 

@@ -70,6 +70,9 @@ def test_conv3x3_fwd_stats_dgrad_wgrad(ops, B, Cin, Fm, T, Cout, nchw):
 POOL_CASES = [  # B,T,F,C,pf,pt,tcf
     (2, 8, 40, 8, 1, 2, False), (2, 8, 40, 128, 1, 2, False), (2, 8, 40, 128, 1, 2, True), (3, 4, 40, 16, 1, 2, True),
     (2, 4, 40, 32, 5, 1, False), (2, 4, 8, 32, 2, 1, True), (2, 8, 8, 16, 2, 2, False), (2, 6, 40, 8, 1, 1, True),
+    # ragged extents: nn.MaxPool2d floors (sed.py:90), the dropped tail still carries the statistics terms of the gradient
+    (2, 9, 40, 16, 1, 2, False), (3, 7, 13, 128, 1, 2, True), (2, 5, 42, 32, 5, 1, False), (2, 11, 9, 16, 2, 4, True),
+    (1, 3, 7, 8, 3, 2, False),
 ]
 
 

@@ -358,7 +358,7 @@ def test_backward_after_second_forward_raises(sed):
 def test_bad_inputs_raise(sed):
     m = sed.TimePooledCRNN(conv_channels=8, dropout=0.0).cuda()
     with pytest.raises(ValueError):
-        m(torch.zeros(2, 1, 40, 60).cuda())            # T not a multiple of 8
+        m(torch.zeros(2, 1, 40, 7).cuda())             # shorter than one output frame (T' = floor(7/8) = 0)
     with pytest.raises(ValueError):
         m(torch.zeros(2, 2, 40, 64).cuda())            # wrong channel count
     with pytest.raises(sed.SedHipError):

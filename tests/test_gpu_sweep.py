@@ -1,0 +1,111 @@
+"""Seeded sweep of random network shapes, HIP path against the CPU oracle (oracle/crnn_ref.py, pinned by goldens g1-g5):
+probabilities, loss, every gradient and the eval forward.  The fixed cases elsewhere pick shapes by hand; this one draws
+them (channel counts that do and do not take the MFMA kernels, mel widths that are odd / narrower than a tile / wider
+than one, sequence lengths that are not a multiple of the pooling product (floor pooling drops the tail, sed.py:90),
+1-3 GRU layers, 1-6 classes, 1-4 conv blocks with time pools of 1, 2 or 4), so a shape-dependent indexing slip in any
+kernel shows up as a parity failure rather than in production."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sed():
+    import sed_crnn_amd
+    return sed_crnn_amd
+
+
+def _draw(seed):
+    r = random.Random(seed)
+    pools = tuple(r.choice([1, 2, 2, 2, 4]) for _ in range(r.choice([1, 2, 3, 3, 3, 4])))
+    prod = 1
+    for p in pools:
+        prod *= p
+    tp = r.randint(1, 9)                                   # GRU steps
+    T = tp * prod + r.randint(0, prod - 1)                 # + a tail the floor pooling drops
+    return dict(B=r.choice([1, 2, 3, 5, 8, 17]), Cin=r.choice([1, 1, 2, 3, 4, 6]), F=r.choice([3, 5, 8, 13, 20, 40, 41, 64, 70]),
+                T=T, Tp=tp, C=r.choice([4, 8, 16, 32, 32, 64, 128]), H=r.choice([4, 8, 16, 32, 64, 128]),
+                L=r.choice([1, 2, 2, 3]), K=r.choice([1, 1, 2, 6]), pools=pools, loss=r.choice(["bce", "bce", "focal"]))
+
+
+def _cmp(a, b, atol, rtol=0.0, msg=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (msg, a.shape, b.shape)
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    assert bool((err <= bound).all()), (msg, float(err.max()), float(b.abs().max()))
+
+
+def _deepest_flip_prone_block(bn_out, pools, margin=5e-6):
+    """ReLU and max-pool are discontinuous in their gradient routing: where a BatchNorm output lies within rounding
+    distance of 0, or the two largest values of a live pooling window within rounding distance of each other, two correct
+    fp32 implementations can route the gradient differently (torch fp32 against torch fp64 does: one flipped gate moves a
+    conv weight gradient by ~1 % of its largest entry at these small sizes).  Returns the deepest conv block holding such
+    an element (-1: none): the gradients of that block and of every block before it get the looser bound."""
+    deepest = -1
+    for l, (z, p) in enumerate(zip(bn_out, pools)):
+        near = int((z.abs() < margin).sum())
+        if p > 1:
+            Tw = z.shape[-1] // p * p
+            w = z[..., :Tw].reshape(*z.shape[:-1], Tw // p, p)
+            top = w.topk(2, dim=-1).values
+            near += int((((top[..., 0] - top[..., 1]) < margin) & (top[..., 0] > -margin)).sum())
+        if near:
+            deepest = l
+    return deepest
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_random_shape_vs_oracle(sed, seed):
+    from oracle import crnn_ref
+    c = _draw(seed)
+    if c["B"] * c["F"] * c["T"] * c["C"] * max(c["Cin"], c["C"]) > 3e9:      # keep the CPU oracle in seconds
+        c["B"] = 2
+    torch.manual_seed(1000 + seed)
+    kw = dict(conv_channels=c["C"], dropout=0.0, in_channels=c["Cin"], n_mels=c["F"], time_pool=c["pools"],
+              gru_hidden=c["H"], gru_layers=c["L"], n_classes=c["K"])
+    ref = crnn_ref.SedNetRef(**kw)
+    m = sed.TimePooledCRNN(**kw)
+    x, y = crnn_ref.synthetic_batch(c["B"], c["Cin"], c["F"], c["T"], c["Tp"], K=c["K"], seed=seed)
+    if c["B"] * c["T"] * c["F"] < 4096:      # few samples per channel make BatchNorm's 1/sigma large: keep it well conditioned
+        x = x * 3.0
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    ref.train()
+    bn_out = []
+    hooks = [bn.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach())) for bn in ref.bns]
+    out_r = ref(x)
+    for h in hooks:
+        h.remove()
+    flip = _deepest_flip_prone_block(bn_out, c["pools"])
+    assert out_r.shape == (c["B"], c["Tp"], c["K"]), (c, out_r.shape)
+    lf = crnn_ref.bce_logits if c["loss"] == "bce" else crnn_ref.focal_bce
+    lr_ = lf(out_r, y)
+    lr_.backward()
+    m.train()
+    out = m(x.cuda())
+    crit = sed.BCEWithLogitsLoss() if c["loss"] == "bce" else sed.FocalBCELoss()
+    lh = crit(out, y.cuda())
+    lh.backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"train probabilities {c}")
+    assert abs(lh.item() - lr_.item()) < 1e-4, c
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        g = rg[k].grad
+        block = int(k.split(".")[1]) if k.startswith(("convs.", "bns.")) else 10 ** 6
+        loose = 5e-2 * float(g.abs().max()) if block <= flip else 0.0          # see _deepest_flip_prone_block
+        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()) + loose, rtol=1e-2, msg=f"{k} {c} flip-prone<= {flip}")
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=1e-3, msg=f"eval probabilities {c}")
+    # BatchNorm running statistics after the one training forward
+    sd, rsd = m.state_dict(), ref.state_dict()
+    for k in rsd:
+        if "running" in k:
+            _cmp(sd[k], rsd[k], atol=1e-5, rtol=1e-4, msg=f"{k} {c}")
+        if "num_batches_tracked" in k:
+            assert int(sd[k]) == int(rsd[k]) == 1
