@@ -646,11 +646,12 @@ def get_model(in_channels=1, n_mels=40, seq_len=256, n_classes=1, conv_channels=
     ``pools`` are (pool_mel, pool_time) per conv block: the fork's time-pooled net is the default; the
     README figure's original SEDnet is ``pools=[(5,1),(2,1),(2,1)], n_classes=6, fc=[16, 6]``.
     ``fc`` lists the dense sizes after the GRUs (ReLU between them); default ``[n_classes]``.
-    ``seq_len`` is validated against the time pooling and otherwise free (the kernels take any T).
+    ``seq_len`` must cover one output frame and is otherwise free (the kernels take any T; a ragged tail is dropped
+    by the pooling like ``nn.MaxPool2d`` does).
     """
     tf = math.prod(p[1] for p in pools)
-    if seq_len % tf:
-        raise ValueError(f"seq_len={seq_len} is not divisible by the total time pooling {tf}")
+    if seq_len < tf:
+        raise ValueError(f"seq_len={seq_len} is shorter than one output frame (total time pooling {tf})")
     fc = [n_classes] if fc is None else list(fc)
     if fc[-1] != n_classes:
         raise ValueError("the last dense size must equal n_classes")

@@ -109,3 +109,147 @@ def test_random_shape_vs_oracle(sed, seed):
             _cmp(sd[k], rsd[k], atol=1e-5, rtol=1e-4, msg=f"{k} {c}")
         if "num_batches_tracked" in k:
             assert int(sd[k]) == int(rsd[k]) == 1
+
+
+def _grads_vs(m, want_of, flip, msg):
+    for k, p in m.named_parameters():
+        g = want_of(k)
+        block = int(k.split(".")[1]) if k.split(".")[0] in ("convs", "bns") else 10 ** 6
+        if k.startswith("conv_stack."):
+            block = int(k.split(".")[1]) // 4
+        loose = 5e-2 * float(g.abs().max()) if block <= flip else 0.0
+        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()) + loose, rtol=1e-2, msg=f"{k} {msg} flip-prone<= {flip}")
+
+
+@pytest.mark.parametrize("seed", list(range(100, 116)))
+def test_random_lightning_variant_vs_oracle(sed, seed):
+    """crnn_lightning.py:41-73 with drawn widths: two single-layer GRUs of different sizes, dense + ReLU + dense, focal loss."""
+    from oracle import crnn_ref
+    r = random.Random(seed)
+    pools = tuple(r.choice([1, 2, 2, 4]) for _ in range(r.choice([2, 3, 3])))
+    prod = 1
+    for p in pools:
+        prod *= p
+    tp = r.randint(1, 10)
+    c = dict(B=r.choice([1, 2, 4, 9]), Cin=r.choice([1, 1, 2, 4]), F=r.choice([6, 16, 40, 45]), T=tp * prod + r.randint(0, prod - 1),
+             depth=r.choice([4, 8, 16, 32, 64]), g1=r.choice([4, 8, 16, 64]), g2=r.choice([4, 8, 12, 32]), d1=r.choice([1, 3, 8, 16]),
+             K=r.choice([1, 1, 3]), pools=pools)
+    torch.manual_seed(seed)
+    ref = crnn_ref.LightningNetRef(dropout=0.0, in_channels=c["Cin"], n_mels=c["F"], conv_depth=c["depth"], time_pool=pools,
+                                   gru1=c["g1"], gru2=c["g2"], dense1=c["d1"], n_classes=c["K"])
+    m = sed.LightningTimePooledCRNN(dropout=0.0, in_channels=c["Cin"], n_mels=c["F"], conv_depth=c["depth"], time_pool=pools,
+                                    gru1_units=c["g1"], gru2_units=c["g2"], dense1_units=c["d1"], n_classes=c["K"],
+                                    seq_len_in=c["T"])
+    x, y = crnn_ref.synthetic_batch(c["B"], c["Cin"], c["F"], c["T"], tp, K=c["K"], seed=seed)
+    if c["B"] * c["T"] * c["F"] < 4096:
+        x = x * 3.0
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    ref.train()
+    bn_out = []
+    hooks = [mod.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach()))
+             for mod in ref.conv_stack if isinstance(mod, torch.nn.BatchNorm2d)]
+    out_r = ref(x)
+    for h in hooks:
+        h.remove()
+    flip = _deepest_flip_prone_block(bn_out, pools)
+    lr_ = crnn_ref.focal_bce(out_r, y)
+    lr_.backward()
+    m.train()
+    out = m(x.cuda())
+    lh = sed.FocalBCELoss()(out, y.cuda())
+    lh.backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"train probabilities {c}")
+    assert abs(lh.item() - lr_.item()) < 1e-5, c
+    rg = dict(ref.named_parameters())
+    _grads_vs(m, lambda k: rg[k].grad, flip, str(c))
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=1e-3, msg=f"eval probabilities {c}")
+
+
+@pytest.mark.parametrize("seed", list(range(200, 220)))
+def test_random_get_model_topology_vs_torch_autograd(sed, seed):
+    """`get_model` (README.md:44; no body in the reference, so parity is unpinned by it) with drawn (mel, time) pools per
+    block, GRU sizes per layer and dense stacks, against autograd of the same graph assembled from torch.nn.functional:
+    mel pooling with ragged mel widths, mixed mel/time pooling, blocks without pooling, up to three dense layers."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    r = random.Random(seed)
+    nb = r.choice([1, 2, 3, 3, 4])
+    pools = [r.choice([(1, 1), (1, 2), (2, 1), (2, 2), (5, 1), (3, 2), (1, 4)]) for _ in range(nb)]
+    pf_all, pt_all = 1, 1
+    for pf, pt in pools:
+        pf_all, pt_all = pf_all * pf, pt_all * pt
+    Fm = pf_all * r.randint(1, 4) + r.randint(0, pf_all - 1)
+    tp = r.randint(1, 8)
+    T = tp * pt_all + r.randint(0, pt_all - 1)
+    C = r.choice([4, 8, 16, 32, 64, 128])
+    hid = [r.choice([4, 8, 16, 32]) for _ in range(r.choice([1, 2, 2, 3]))]
+    K = r.choice([1, 2, 6])
+    fc = [r.choice([2, 8, 16]) for _ in range(r.choice([0, 1, 1, 2]))] + [K]
+    B, cin = r.choice([1, 2, 3, 6]), r.choice([1, 2, 3, 6])
+    if B * Fm * T * C * max(cin, C) > 2e9:
+        B = 1
+    msg = f"pools={pools} F={Fm} T={T} C={C} hid={hid} fc={fc} B={B} cin={cin}"
+    torch.manual_seed(seed)
+    m = sed.get_model(in_channels=cin, n_mels=Fm, seq_len=T, n_classes=K, conv_channels=C, pools=pools, rnn_hidden=hid,
+                      fc=fc, dropout=0.0)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in m.state_dict().items()}
+    m.cuda()
+    x = torch.randn(B, cin, Fm, T) * (3.0 if B * T * Fm < 4096 else 1.0)
+    y = (torch.rand(B, tp, K) > 0.7).float()
+    f_out = Fm
+    for pf, _ in pools:
+        f_out //= pf
+    grus, width = [], C * f_out
+    for i, h in enumerate(hid):
+        g = nn.GRU(width, h, batch_first=True, bidirectional=True)
+        g.load_state_dict({k.split(".", 2)[2]: v.detach() for k, v in sd.items() if k.startswith(f"grus.{i}.")})
+        grus.append(g)
+        width = 2 * h
+    bn_out = []
+
+    def ref_fwd(x):
+        h = x
+        for l, (pf, pt) in enumerate(pools):
+            h = F.conv2d(h, sd[f"convs.{l}.weight"], sd[f"convs.{l}.bias"], padding=1)
+            h = F.batch_norm(h, None, None, sd[f"bns.{l}.weight"], sd[f"bns.{l}.bias"], training=True)
+            bn_out.append(h.detach())
+            h = F.max_pool2d(torch.relu(h), (pf, pt))
+        b, c, f, t = h.shape
+        h = h.permute(0, 3, 1, 2).reshape(b, t, c * f)
+        for g in grus:
+            h, _ = g(h)
+        for j in range(len(fc)):
+            h = F.linear(h, sd[f"fcs.{j}.weight"], sd[f"fcs.{j}.bias"])
+            if j + 1 < len(fc):
+                h = torch.relu(h)
+        return h
+    out_r = ref_fwd(x)
+    assert out_r.shape == (B, tp, K), msg
+    loss_r = F.binary_cross_entropy_with_logits(out_r, y)
+    loss_r.backward()
+    # flip-prone elements: zero crossings, and near-ties inside a live (pf x pt) window
+    flip = -1
+    for l, (z, (pf, pt)) in enumerate(zip(bn_out, pools)):
+        near = int((z.abs() < 5e-6).sum())
+        if pf * pt > 1:
+            w = F.unfold(z.reshape(-1, 1, z.shape[2], z.shape[3]), (pf, pt), stride=(pf, pt))      # [N, pf*pt, windows]
+            top = w.topk(2, dim=1).values
+            near += int((((top[:, 0] - top[:, 1]) < 5e-6) & (top[:, 0] > -5e-6)).sum())
+        if near:
+            flip = l
+    m.train()
+    out = m(x.cuda())
+    loss = sed.BCEWithLogitsLoss()(out, y.cuda())
+    loss.backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=msg)
+    assert abs(loss.item() - loss_r.item()) < 1e-4, msg
+
+    def want(k):
+        if k.startswith("grus."):
+            return dict(grus[int(k.split(".")[1])].named_parameters())[k.split(".", 2)[2]].grad
+        return sd[k].grad
+    _grads_vs(m, want, flip, msg)
