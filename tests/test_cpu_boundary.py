@@ -55,8 +55,12 @@ def test_net_workspace_and_shapes_for_baseline_configs():
     assert 2e9 < tr < 6e9 and ev < tr                   # ~3 GB of activations at B=128: trivial vs 288 GB HBM
     m5 = sed.TimePooledCRNN(conv_channels=128, dropout=0.5, in_channels=4, n_mels=128, gru_hidden=256)
     assert _lib.lib().sed_net_workspace_bytes(C.byref(m5._cfg(128, 512)), 1) > 0      # config 5 is plannable
+    ragged = m._cfg(128, 256)
+    ragged.pool_t[0] = 3                                # floor pooling like nn.MaxPool2d: 256 -> 85 -> 42 -> 21
+    assert _lib.lib().sed_net_workspace_bytes(C.byref(ragged), 1) > 0
+    assert _lib.lib().sed_net_out_shape(C.byref(ragged), C.byref(tp), C.byref(fp)) == 0 and (tp.value, fp.value) == (21, 40)
     bad = m._cfg(128, 256)
-    bad.pool_t[0] = 3
+    bad.pool_t[0] = 300                                 # longer than the sequence: no output frame
     assert _lib.lib().sed_net_workspace_bytes(C.byref(bad), 1) == 0
 
 
