@@ -14,6 +14,7 @@
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
 #include "common.h"
+#include <type_traits>
 
 #define CV_CIC 32   // input channels per LDS chunk
 #define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
@@ -23,7 +24,7 @@
 #define WG_ND 10     // wgrad: DMA items (float4) per thread of the dY tile     (2*WG_FT*32    <= 256*WG_ND)
 
 #define CV_TPAD 56   // fwd: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
-#define CV_NH 8      // fwd: max float4 per thread of the halo tile ((TT+2)*(FT+2)*8 <= 256*CV_NH)
+#define CV_NH 8      // fwd (the fp32 kernel's vmcnt(12) = 4 + CV_NH is written out in its asm): max float4 per thread of the halo tile ((TT+2)*(FT+2)*8 <= 256*CV_NH)
 
 struct ConvPlan {
     int kind;       // 0 small, 1 mfma, -1 unsupported
@@ -360,74 +361,111 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+    // Halo staging.  Every lane issues all CV_NH loads of a chunk from a clamped (always valid) address and zeroes the
+    // out-of-range ones when it commits them: a fixed number of load instructions per chunk is what lets the hand-counted
+    // vmcnt waits of the weight fragments below step over a halo prefetch in flight.
     f32x4 ph[CV_NH];
     int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+    unsigned hoff[CV_NH];                 // element offset of each staged float4 in x, chunk 0
+    unsigned hmask = 0;                   // bit u: the float4 is inside the input (else zero padding)
 #pragma unroll
     for (int u = 0; u < CV_NH; ++u) {
         int i = tid + u * 256;
-        int row = i >> 3, tt = sed_fdiv(row, invF2);
-        pdst[u] = (i < HR * 8) ? tt * TP + (row - tt * F2) * CV_LD + (i & 7) * 4 : -1;
+        int row = i >> 3, tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+        pdst[u] = (i < HR * 8) ? tt * TP + ff * CV_LD + (i & 7) * 4 : -1;
+        int t = t0 + tt - 1, f = f0 + ff - 1;
+        if (i < HR * 8 && t >= 0 && t < T && f >= 0 && f < F) hmask |= 1u << u;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+        hoff[u] = (((unsigned)b * T + t) * F + f) * Cin + (i & 7) * 4;       // < 2^32 elements: checked by the host
     }
+    // Both kinds of global load in the loop are issued from inline asm and waited for with hand-counted vmcnt (see the
+    // weight fragments below): left to hipcc, the conditional prefetch made it wait for everything outstanding before each
+    // re-issue into the staging registers.
     auto fetch = [&](int cc) {
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
-            int i = tid + u * 256;
-            f32x4 v = {0, 0, 0, 0};
-            if (i < HR * 8) {
-                int row = i >> 3, q = i & 7;
-                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-                int t = t0 + tt - 1, f = f0 + ff - 1;
-                if (t >= 0 && t < T && f >= 0 && f < F)
-                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
-            }
-            ph[u] = v;
+            const float* pu = x + (size_t)hoff[u] + cc * CV_CIC;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ph[u]) : "v"(pu));
         }
     };
-    auto commit = [&](float* buf) {
+    auto commit = [&](float* buf) {       // caller: the loads have retired (a vmcnt wait that covers them has been executed)
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) asm volatile("" : "+v"(ph[u]));
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
-            if (pdst[u] >= 0) *(f32x4*)(buf + pdst[u]) = ph[u];
+            if (pdst[u] >= 0) *(f32x4*)(buf + pdst[u]) = ((hmask >> u) & 1) ? ph[u] : (f32x4){0, 0, 0, 0};
         }
     };
+    // Weight fragments: four 1 KiB wave loads per (chunk, tap) step, straight from L2 in MFMA B-fragment order, one step
+    // ahead.  They are issued from inline asm and waited for with hand-counted vmcnt: hipcc's own counting gives up at the
+    // loop back-edge and waited for the loads it had just issued (vmcnt(1) at the first MFMA of every tap: the L2 round trip
+    // exposed nine times per chunk, and with it the halo prefetch, which retires in order in front of them).
     const f32x4* wl = (const f32x4*)wq + (size_t)cot * 64 + lane;
     auto load_b = [&](f32x4* bq, int cc, int tap) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = wl[(((size_t)tap * nchunks + cc) * 4 + g) * ncot * 64];
+        for (int g = 0; g < 4; ++g) {
+            const f32x4* pg = wl + (((size_t)tap * nchunks + cc) * 4 + g) * ncot * 64;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[g]) : "v"(pg));
+        }
+    };
+    auto bind = [&](f32x4* bq) {          // the fragments are valid from here on (orders their uses after the wait)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[g]));
     };
 
     fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)");
     commit(smem);
-    f32x4 bf[4];
-    load_b(bf, 0, 0);
+    f32x4 bfs[2][4];
+    load_b(bfs[0], 0, 0);
     __syncthreads();
-    for (int cc = 0; cc < nchunks; ++cc) {
+    const int nsteps = 9 * nchunks;                       // (chunk, tap) steps, two per loop iteration: the two register sets
+    auto step = [&](int st, int cc, int tap, f32x4* cur, f32x4* nxt) {      // swap roles without a copy
         const bool more = cc + 1 < nchunks;
-        if (more) fetch(cc + 1);
+        const bool last = st + 1 >= nsteps;
+        if (!last) load_b(nxt, tap < 8 ? cc : cc + 1, tap < 8 ? tap + 1 : 0);
+        if (tap == 0 && more) fetch(cc + 1);              // AFTER the tap-1 fragments: vmcnt retires in order
+        __builtin_amdgcn_sched_barrier(0);
+        // `cur` was issued one step ago.  Younger than it: this step's 4 fragment loads and, in taps 0 and 1 of a chunk that
+        // prefetches, the CV_NH halo loads issued in tap 0.  (A smaller count than necessary only waits longer.)
+        // Measured alternatives: one load per 8-k group spread over the tap (-4 %), nine taps fully unrolled (-2 %).
+        if (last) asm volatile("s_waitcnt vmcnt(0)");
+        else if (more && tap < 2) asm volatile("s_waitcnt vmcnt(12)");      // 4 + CV_NH
+        else asm volatile("s_waitcnt vmcnt(4)");
+        bind(cur);
         const float* halo = smem + (cc & 1) * HB;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            f32x4 bn[4];
-            if (tap < 8) load_b(bn, cc, tap + 1);
-            else if (more) load_b(bn, cc + 1, 0);
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = kw * TP + kh * CV_LD;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = kw * TP + kh * CV_LD;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 af[CV_MTW];
+        for (int g = 0; g < 4; ++g) {
+            f32x4 af[CV_MTW];
 #pragma unroll
-                for (int i = 0; i < CV_MTW; ++i)
-                    af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
+            for (int i = 0; i < CV_MTW; ++i)
+                af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < CV_MTW; ++i)      // tiles past nMT read clamped rows and are never stored
-                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[g][j], acc[i], 0, 0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bf[g] = bn[g];
+                for (int i = 0; i < CV_MTW; ++i)          // tiles past nMT read clamped rows and are never stored
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], cur[g][j], acc[i], 0, 0, 0);
         }
-        if (more) commit(smem + ((cc + 1) & 1) * HB);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8) {
+            if (more) commit(smem + ((cc + 1) & 1) * HB);     // prefetched in tap 0: retired by the vmcnt(4) of taps 2..8
+            __syncthreads();
+        }
+    };
+    {
+        int cc = 0, tap = 0;
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 2) {
+            step(st, cc, tap, bfs[0], bfs[1]);
+            if (++tap == 9) { tap = 0; ++cc; }
+            if (st + 1 < nsteps) {
+                step(st + 1, cc, tap, bfs[1], bfs[0]);
+                if (++tap == 9) { tap = 0; ++cc; }
+            }
+        }
     }
 
     // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
@@ -441,37 +479,48 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     float s1 = 0.f, s2 = 0.f;
     float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
     const int rq = lane >> 3, c4 = (lane & 7) * 4;
+    // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
+    const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
+    auto store_tiles = [&](auto checked) {
+        constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
-    for (int i = 0; i < CV_MTW; ++i) {
-        int mt = mp + i * MPARTS;
-        if (mt < nMT) {
+        for (int i = 0; i < CV_MTW; ++i) {
+            int mt = mp + i * MPARTS;
+            if (mt < nMT) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-                int p = mt * 32 + row;
-                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                float v = acc[i][j] + bv;
-                tsc[row * 32 + r] = v;
-                if (p < MROWS && t0 + tl < T && f < F) {
-                    s1 += v;
-                    s2 += v * v;
+                for (int j = 0; j < 16; ++j) {
+                    int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    float v = acc[i][j] + bv;
+                    tsc[row * 32 + r] = v;
+                    bool ok = true;
+                    if (CHK) {
+                        int p = mt * 32 + row;
+                        int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                        ok = p < MROWS && t0 + tl < T && f < F;
+                    }
+                    if (ok) {
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
-            __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int row = rq + 8 * k;
-                int p = mt * 32 + row;
-                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
-                if (p < MROWS && t0 + tl < T && f < F)
-                    *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                for (int k = 0; k < 4; ++k) {
+                    int row = rq + 8 * k;
+                    int p = mt * 32 + row;
+                    int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                    f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                    if (!CHK || (p < MROWS && t0 + tl < T && f < F))
+                        *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-    }
+    };
+    if (interior) store_tiles(std::false_type{});
+    else store_tiles(std::true_type{});
     if (stat) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -734,6 +783,9 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
                 SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<1, 2>), p.lds));
                 conv3x3_mfma_fwd_bf16x3_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
             }
+        } else if ((size_t)B * T * F * Cin >= ((size_t)1 << 32)) {
+            sed_set_error("conv3x3_fwd: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernel", (size_t)B * T * F * Cin);
+            return -1;
         } else if (p.nct == 4) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
             conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
