@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsedcrnn.so")
+# SED_CRNN_LIB: another build of the same library (A/B measurements of a kernel change on one box); default in-tree
+LIB_PATH = os.environ.get("SED_CRNN_LIB") or os.path.join(HERE, "libsedcrnn.so")
 
 SED_MAX_CONV = 4
 SED_MAX_GRU = 4
