@@ -1,0 +1,1376 @@
+#ifndef SED_ABL
+#define SED_ABL 0
+#endif
+// conv.hip — 3x3 / stride 1 / zero-pad 1 convolution over (mel, time), channels-last.
+//
+// Replaces aten::mkldnn_convolution / convolution_backward reached from nn.Conv2d at
+// reference sed.py:88,107 and crnn_lightning.py:47.
+//
+// Two code paths (gfx950 only):
+//   * small  : Cin*Cout small (first layer, Cin in {1,2,4}; the 16-channel Lightning net).
+//              Direct VALU convolution, HBM-bound: coalesced 16 B/lane channel-last stores,
+//              mel-band halo tile in LDS; weights in registers (Cin <= 4) or LDS.
+//   * mfma   : Cin%32==0, Cout%32==0 (the 128-channel layers, K = 9*Cin = 1152): implicit GEMM
+//              on v_mfma_f32_32x32x2_f32 (exact fp32), (TT+2)x(FT+2) halo tile of 32 input
+//              channels in LDS read with conflict-free ds_read_b128 (TT time rows x FT mel columns per
+//              block, any mel width), weights streamed L2 -> registers in MFMA fragment order.
+// Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
+// conv output is not re-read for the statistics.
+#include "common.h"
+#include <type_traits>
+
+#define CV_CIC 32   // input channels per LDS chunk
+#define CV_LD 36    // padded LDS row (floats): 16-B slots 9*row -> conflict-free ds_read_b128
+#define CV_MTW 5    // max 32-row tiles per wave
+#define WG_FT 40     // wgrad: max mel columns per tile (2 time rows at that width; TT*FT <= 2*WG_FT)
+#define WG_NX 6      // wgrad: DMA items (float4) per thread of the halo tile   (4*(WG_FT+2)*8 <= 256*WG_NX)
+#define WG_ND 10     // wgrad: DMA items (float4) per thread of the dY tile     (2*WG_FT*32    <= 256*WG_ND)
+
+#define CV_TPAD 56   // fwd: extra floats per halo time-row (bank-conflict-free mel wrap-around, see kernel)
+#define CV_NH 8      // fwd (the fp32 kernel's vmcnt(12) = 4 + CV_NH is written out in its asm): max float4 per thread of the halo tile ((TT+2)*(FT+2)*8 <= 256*CV_NH)
+
+struct ConvPlan {
+    int kind;       // 0 small, 1 mfma, -1 unsupported
+    int TT;         // time rows per block tile
+    int FT, nft;    // mfma: mel columns per block tile, mel tiles (FT == F, nft == 1 on the small path)
+    int nct;        // mfma: 32-wide co tiles per block
+    int tblocks;    // ceil(T/TT)
+    int rows;       // stat partial rows = B * tblocks * nft
+    size_t lds;
+};
+
+// MFMA block tile: TT time rows x FT mel columns (+1 halo each side) with TT*FT <= limit output rows (every wave always
+// runs its CV_MTW 32-row tiles, so rows below the limit are idle MFMA cycles) and at most 256*CV_NH/8 halo rows.
+// Score = useful share of the MFMA rows (tile fill x mel coverage x time coverage), discounted by the halo share that is
+// staged per tile; measured on MI355X at F=128: 32x5 125 TFLOP/s, 26x6 119, 32x4 102, 64x1 54.
+static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nft_out) {
+    double best = -1.0;
+    int last_ft = -1;
+    for (int nft = 1; nft <= F; ++nft) {
+        int FT = cdiv(F, nft);
+        FT += FT & 1;                                    // even (the weight-gradient kernel walks mel pairs)
+        if (FT == last_ft) continue;
+        last_ft = FT;
+        const int nf = cdiv(F, FT);
+        // tall tiles (TT > 8) only for a full-width narrow mel axis (the mel-pooled topologies: F = 8, 4 after pooling),
+        // and only while two blocks still fit the LDS of a CU
+        const int tt_max = (nft == 1) ? 64 : 8;
+        for (int TT = 1; TT <= tt_max && TT <= T; ++TT) {
+            if (TT * FT > limit || (TT + 2) * (FT + 2) * 8 > 256 * CV_NH) continue;
+            if (TT > 8 && (size_t)2 * (TT + 2) * ((FT + 2) * CV_LD + CV_TPAD) * sizeof(float) > 80 * 1024) continue;
+            double util = ((double)(TT * FT) / limit) * ((double)F / ((double)nf * FT)) * ((double)T / ((double)cdiv(T, TT) * TT));
+            double score = util / (1.0 + 0.25 * ((double)(TT + 2) * (FT + 2) / (TT * FT) - 1.0));
+            if (score > best) { best = score; *TT_out = TT; *FT_out = FT; *nft_out = nf; }
+        }
+        if (FT <= 2) break;
+    }
+    return best > 0.0;
+}
+
+static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+    ConvPlan p{};
+    p.kind = -1;
+    p.FT = F; p.nft = 1;
+    if (!x_is_nchw && Cin % CV_CIC == 0 && Cout % 32 == 0) {
+        int nct = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0 ? 2 : 1);
+        int mparts = 4 / nct;
+        int limit = 32 * CV_MTW * mparts;
+        if (!conv_tile(F, T, limit, &p.TT, &p.FT, &p.nft)) return p;
+        p.kind = 1; p.nct = nct;
+        p.lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
+        const size_t epi = (size_t)(4 * 1024 + 256) * sizeof(float);      // epilogue: four 32x32 transpose scratches + the stat exchange
+        if (p.lds < epi) p.lds = epi;
+    }
+    if (p.kind < 0) {
+        if (Cout % 4 != 0) return p;
+        int TT = 4;
+        if (TT > T) TT = T;
+        size_t lds = ((size_t)9 * Cin * Cout + (size_t)(TT + 2) * (F + 2) * Cin) * sizeof(float);
+        size_t red = (size_t)2 * 256 * 4 * sizeof(float);
+        if (lds < red) lds = red;
+        if (lds > 150 * 1024) return p;
+        p.kind = 0; p.TT = TT; p.nct = 0; p.lds = lds;
+    }
+    p.tblocks = cdiv(T, p.TT);
+    p.rows = B * p.tblocks * p.nft;
+    return p;
+}
+
+// ───────────────────────── weight packing ─────────────────────────
+// MFMA fragment order of a (Cin -> Cout) tap matrix: [tap][ci/32][ (ci%32)/8 ][co/32][lane = co%32 + 32*((ci%8)/4)][ci%4]
+// i.e. exactly the B operand of v_mfma_f32_32x32x2_f32 for 4 consecutive k-steps, 1 KiB per wave-load.
+__host__ __device__ inline size_t conv_frag_index(int tap, int co, int ci, int Cout, int Cin) {
+    int cc = ci >> 5, g = (ci & 31) >> 3, h = (ci & 7) >> 2, j = ci & 3;
+    int cot = co >> 5, r = co & 31;
+    return ((((((size_t)tap * (Cin >> 5) + cc) * 4 + g) * (Cout >> 5) + cot) * 64) + r + 32 * h) * 4 + j;
+}
+
+__global__ void conv_pack_w_k(const float* __restrict__ w, float* __restrict__ wf,
+                              float* __restrict__ wd, int Cout, int Cin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cout * Cin * 9;
+    if (i >= n) return;
+    int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    float v = w[i];
+    const bool frag = (Cin % 32 == 0) && (Cout % 32 == 0);
+    if (wf) wf[frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
+    // dgrad: dx[pos][ci] = sum_tap' sum_co dy[pos + tap' - 1][co] * w[co][ci][flip(tap')]  (a Cout -> Cin conv)
+    if (wd) wd[frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+}
+
+extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(w && Cout > 0 && Cin > 0, "conv3x3_pack_weights: bad arguments");
+    int n = Cout * Cin * 9;
+    conv_pack_w_k<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(w, wf, wd, Cout, Cin);
+    SED_LAUNCH_CHECK("conv_pack_w");
+    return 0;
+}
+
+// ── 3-term bf16-split path (EXPERIMENT, explicit opt-in: mode 1 of the *_ex entries; never the default) ──
+// w = hi + lo with hi = bf16(w), lo = bf16(w - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate): three bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles, i.e. 5.3x the matrix
+// rate; the dropped lo*lo term and the 16-bit split leave a relative error of ~4e-6 on a K = 1152 sum (fp32: 3e-7).
+// Fragment order: [tap][ci/32][(ci%32)/16][co/32][hi|lo][lane = co%32 + 32*((ci%16)/8)][ci%8] bf16 — the B operand of one
+// 32x32x16 MFMA per 1 KiB wave-load; same byte count as the fp32 packing, so it lives in the same workspace region.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline size_t conv_frag_index_b(int tap, int co, int ci, int Cout, int Cin, int part) {
+    int cc = ci >> 5, g = (ci & 31) >> 4, h = (ci & 15) >> 3, j = ci & 7;
+    int cot = co >> 5, r = co & 31;
+    return (((((((size_t)tap * (Cin >> 5) + cc) * 2 + g) * (Cout >> 5) + cot) * 2 + part) * 64) + r + 32 * h) * 8 + j;
+}
+
+__global__ void conv_pack_w_bf16x3_k(const float* __restrict__ w, __bf16* __restrict__ wf, __bf16* __restrict__ wd, int Cout, int Cin) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cout * Cin * 9;
+    if (i >= n) return;
+    int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+    if (wf) { wf[conv_frag_index_b(tap, co, ci, Cout, Cin, 0)] = hi; wf[conv_frag_index_b(tap, co, ci, Cout, Cin, 1)] = lo; }
+    if (wd) { wd[conv_frag_index_b(8 - tap, ci, co, Cin, Cout, 0)] = hi; wd[conv_frag_index_b(8 - tap, ci, co, Cin, Cout, 1)] = lo; }
+}
+
+extern "C" int sed_conv3x3_pack_weights_ex(const float* w, float* wf, float* wd, int Cout, int Cin, int mode, void* stream) {
+    if (mode == 0 || Cin % 32 != 0 || Cout % 32 != 0) return sed_conv3x3_pack_weights(w, wf, wd, Cout, Cin, stream);
+    SED_REQUIRE(mode == 1, "conv3x3_pack_weights_ex: unknown mode %d", mode);
+    SED_REQUIRE(w && Cout > 0 && Cin > 0, "conv3x3_pack_weights_ex: bad arguments");
+    int n = Cout * Cin * 9;
+    conv_pack_w_bf16x3_k<<<cdiv(n, 256), 256, 0, as_stream(stream)>>>(w, (__bf16*)wf, (__bf16*)wd, Cout, Cin);
+    SED_LAUNCH_CHECK("conv_pack_w_bf16x3");
+    return 0;
+}
+
+// ───────────────────────── small direct forward ─────────────────────────
+__global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* w_s = smem;                        // [9][Cin][Cout]
+    float* halo = smem + 9 * Cin * Cout;      // [TT+2][F+2][Cin]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int F2 = F + 2;
+
+    for (int i = tid; i < 9 * Cin * Cout; i += 256) {
+        int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+        w_s[(tap * Cin + ci) * Cout + co] = wp[i];
+    }
+    const int hn = (TT + 2) * F2 * Cin;
+    if (x_nchw) {
+        for (int i = tid; i < hn; i += 256) {         // tt fastest: time is contiguous in NCHW
+            int tt = i % (TT + 2), ff = (i / (TT + 2)) % F2, ci = i / ((TT + 2) * F2);
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * Cin + ci) * F + f) * T + t];
+            halo[(tt * F2 + ff) * Cin + ci] = v;
+        }
+    } else {
+        for (int i = tid; i < hn; i += 256) {
+            int ci = i % Cin, ff = (i / Cin) % F2, tt = i / (Cin * F2);
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * T + t) * F + f) * Cin + ci];
+            halo[i] = v;
+        }
+    }
+    __syncthreads();
+
+    const int ncg = Cout >> 2;
+    const int nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (active) {
+        f32x4 bv = {0, 0, 0, 0};
+        if (bias) bv = *(const f32x4*)(bias + cg * 4);
+        for (int p = slot; p < TT * F; p += nslots) {
+            int tl = p / F, f = p - tl * F;
+            if (t0 + tl >= T) break;
+            f32x4 acc = bv;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * Cin;
+                    const float* wq = w_s + ((kh * 3 + kw) * Cin) * Cout + cg * 4;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        float xv = hp[ci];
+                        f32x4 w4 = *(const f32x4*)(wq + ci * Cout);
+                        acc += xv * w4;
+                    }
+                }
+            *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4) = acc;
+            s1 += acc;
+            s2 += acc * acc;
+        }
+    }
+    if (stat) {
+        __syncthreads();
+        float* red = smem;                     // [2][nslots][Cout]
+        if (active) {
+            *(f32x4*)(red + (slot)*Cout + cg * 4) = s1;
+            *(f32x4*)(red + (nslots + slot) * Cout + cg * 4) = s2;
+        }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * Cout; i += 256) {
+            int which = i / Cout, co = i - which * Cout;
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * Cout + co];
+            stat[row * 2 * Cout + i] = a;
+        }
+    }
+}
+
+// small, Cin <= 4: the 9*CIN weight float4 of a thread's four output channels live in registers (the generic kernel
+// reads them from LDS for every FMA group, which bounds it at ~1.7 TB/s of output at Cin = 4); LDS holds the halo only.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_fwd_c_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, int TT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;                       // [TT+2][F+2][CIN]; reused as [2][nslots][Cout] for the statistics
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int F2 = F + 2;
+    const int ncg = Cout >> 2;
+    const int nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+
+    f32x4 w[9 * CIN];
+    f32x4 bv = {0, 0, 0, 0};
+    if (active) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[tap * CIN + ci][k] = wp[((size_t)tap * Cout + cg * 4 + k) * CIN + ci];
+        if (bias) bv = *(const f32x4*)(bias + cg * 4);
+    }
+    const int hn = (TT + 2) * F2 * CIN;
+    for (int i = tid; i < hn; i += 256) {
+        int tt, ff, ci;
+        if (x_nchw) { tt = i % (TT + 2); ff = (i / (TT + 2)) % F2; ci = i / ((TT + 2) * F2); }   // time contiguous in NCHW
+        else { ci = i % CIN; ff = (i / CIN) % F2; tt = i / (CIN * F2); }
+        int t = t0 + tt - 1, f = ff - 1;
+        float v = 0.f;
+        if (t >= 0 && t < T && f >= 0 && f < F)
+            v = x_nchw ? x[(((size_t)b * CIN + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * CIN + ci];
+        halo[(tt * F2 + ff) * CIN + ci] = v;
+    }
+    __syncthreads();
+
+    f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
+    if (active) {
+        for (int p = slot; p < TT * F; p += nslots) {
+            int tl = p / F, f = p - tl * F;
+            if (t0 + tl >= T) break;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc += hp[ci] * w[(kh * 3 + kw) * CIN + ci];
+                }
+            *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4) = acc;
+            s1 += acc;
+            s2 += acc * acc;
+        }
+    }
+    if (stat) {
+        __syncthreads();
+        float* red = smem;                     // [2][nslots][Cout]
+        if (active) {
+            *(f32x4*)(red + (slot)*Cout + cg * 4) = s1;
+            *(f32x4*)(red + (nslots + slot) * Cout + cg * 4) = s2;
+        }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        for (int i = tid; i < 2 * Cout; i += 256) {
+            int which = i / Cout, co = i - which * Cout;
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * Cout + co];
+            stat[row * 2 * Cout + i] = a;
+        }
+    }
+}
+
+// ───────────────────────── MFMA implicit-GEMM forward ─────────────────────────
+// grid (ceil(T/TT) * nft, B, Cout/(32*NCT)); 256 threads = 4 waves; block tile = TT time rows x FT mel columns.
+// wave w: co tile ct = w % NCT, row part mp = w / NCT; row tiles mt = mp + i*(4/NCT).
+// Weights are streamed L2 -> registers in fragment order (one coalesced 1 KiB load per wave and k-group, no LDS, no
+// per-tap barrier); the halo tile is double-buffered in LDS with the next 32-channel chunk's global loads issued before
+// the MFMA loop of the current one: one barrier per chunk.
+template <int NCT, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft) {
+    constexpr int MPARTS = 4 / NCT;
+    constexpr int WROWS = 32 * NCT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    // LDS pitch of one halo time-row: F2 rows of CV_LD floats + CV_TPAD.  The pad makes the 16-B slot of flattened
+    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = FT*9 mod 16),
+    // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
+    const int TP = F2 * CV_LD + CV_TPAD;
+    const int HB = (TT + 2) * TP;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tb = blockIdx.x / nft, f0 = (blockIdx.x - tb * nft) * FT;
+    const int b = blockIdx.y, t0 = tb * TT, co0 = blockIdx.z * WROWS;
+    const int ct = wave % NCT, mp = wave / NCT;
+    const int MROWS = TT * FT;
+    const int nMT = (MROWS + 31) >> 5;
+    const int nchunks = Cin / CV_CIC, ncot = Cout >> 5, cot = blockIdx.z * NCT + ct;
+
+    int abase[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int p = (mp + i * MPARTS) * 32 + r;
+        if (p >= MROWS) p = MROWS - 1;
+        int tl = sed_fdiv(p, invF), f = p - tl * FT;
+        abase[i] = tl * TP + f * CV_LD + 4 * h;
+    }
+    f32x16 acc[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    // Halo staging.  Every lane issues all CV_NH loads of a chunk from a clamped (always valid) address and zeroes the
+    // out-of-range ones when it commits them: a fixed number of load instructions per chunk is what lets the hand-counted
+    // vmcnt waits of the weight fragments below step over a halo prefetch in flight.
+    f32x4 ph[CV_NH];
+    int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+    unsigned hoff[CV_NH];                 // element offset of each staged float4 in x, chunk 0
+    unsigned hmask = 0;                   // bit u: the float4 is inside the input (else zero padding)
+#pragma unroll
+    for (int u = 0; u < CV_NH; ++u) {
+        int i = tid + u * 256;
+        int row = i >> 3, tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+        pdst[u] = (i < HR * 8) ? tt * TP + ff * CV_LD + (i & 7) * 4 : -1;
+        int t = t0 + tt - 1, f = f0 + ff - 1;
+        if (i < HR * 8 && t >= 0 && t < T && f >= 0 && f < F) hmask |= 1u << u;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+        hoff[u] = (((unsigned)b * T + t) * F + f) * Cin + (i & 7) * 4;       // < 2^32 elements: checked by the host
+    }
+    // Both kinds of global load in the loop are issued from inline asm and waited for with hand-counted vmcnt (see the
+    // weight fragments below): left to hipcc, the conditional prefetch made it wait for everything outstanding before each
+    // re-issue into the staging registers.
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            const float* pu = x + (size_t)hoff[u] + cc * CV_CIC;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ph[u]) : "v"(pu));
+        }
+    };
+    auto commit = [&](float* buf) {       // caller: the loads have retired (a vmcnt wait that covers them has been executed)
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) asm volatile("" : "+v"(ph[u]));
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            if (pdst[u] >= 0) *(f32x4*)(buf + pdst[u]) = ((hmask >> u) & 1) ? ph[u] : (f32x4){0, 0, 0, 0};
+        }
+    };
+    // Weight fragments: four 1 KiB wave loads per (chunk, tap) step, straight from L2 in MFMA B-fragment order, one step
+    // ahead.  They are issued from inline asm and waited for with hand-counted vmcnt: hipcc's own counting gives up at the
+    // loop back-edge and waited for the loads it had just issued (vmcnt(1) at the first MFMA of every tap: the L2 round trip
+    // exposed nine times per chunk, and with it the halo prefetch, which retires in order in front of them).
+    const f32x4* wl = (const f32x4*)wq + (size_t)cot * 64 + lane;
+    auto load_b = [&](f32x4* bq, int cc, int tap) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4* pg = (SED_ABL & 32) ? wl + (size_t)g * ncot * 64 : wl + (((size_t)tap * nchunks + cc) * 4 + g) * ncot * 64;
+            if ((SED_ABL & 64) && g >= 2) pg = wl + (((size_t)tap * nchunks + cc) * 4 + (g - 2)) * ncot * 64;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[g]) : "v"(pg));
+        }
+    };
+    auto bind = [&](f32x4* bq) {          // the fragments are valid from here on (orders their uses after the wait)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(bq[g]));
+    };
+
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)");
+    commit(smem);
+    f32x4 bfs[2][4];
+    load_b(bfs[0], 0, 0);
+    __syncthreads();
+    const int nsteps = 9 * nchunks;                       // (chunk, tap) steps, two per loop iteration: the two register sets
+    auto step = [&](int st, int cc, int tap, f32x4* cur, f32x4* nxt) {      // swap roles without a copy
+        const bool more = cc + 1 < nchunks;
+        const bool last = st + 1 >= nsteps;
+        if (!last) load_b(nxt, tap < 8 ? cc : cc + 1, tap < 8 ? tap + 1 : 0);
+        if (tap == 0 && more) fetch(cc + 1);              // AFTER the tap-1 fragments: vmcnt retires in order
+        __builtin_amdgcn_sched_barrier(0);
+        // `cur` was issued one step ago.  Younger than it: this step's 4 fragment loads and, in taps 0 and 1 of a chunk that
+        // prefetches, the CV_NH halo loads issued in tap 0.  (A smaller count than necessary only waits longer.)
+        // Measured alternatives: one load per 8-k group spread over the tap (-4 %), nine taps fully unrolled (-2 %).
+        if (last) asm volatile("s_waitcnt vmcnt(0)");
+        else if (more && tap < 2) asm volatile("s_waitcnt vmcnt(12)");      // 4 + CV_NH
+        else asm volatile("s_waitcnt vmcnt(4)");
+        bind(cur);
+        const float* halo = smem + (cc & 1) * HB;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = kw * TP + kh * CV_LD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 af[CV_MTW];
+#pragma unroll
+            for (int i = 0; i < CV_MTW; ++i)
+                af[i] = *(const f32x4*)(halo + abase[i] + toff + g * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i)          // tiles past nMT read clamped rows and are never stored
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], cur[g][j], acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8) {
+            if (more) commit(smem + ((cc + 1) & 1) * HB);     // prefetched in tap 0: retired by the vmcnt(4) of taps 2..8
+            __syncthreads();
+        }
+    };
+    {
+        int cc = 0, tap = 0;
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 2) {
+            step(st, cc, tap, bfs[0], bfs[1]);
+            if (++tap == 9) { tap = 0; ++cc; }
+            if (st + 1 < nsteps) {
+                step(st + 1, cc, tap, bfs[1], bfs[0]);
+                if (++tap == 9) { tap = 0; ++cc; }
+            }
+        }
+    }
+
+    // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
+    // directly is 80 global_store_dword per lane and tile set, 128-byte pieces: store-issue bound, and with both co-resident
+    // workgroups of a CU in lock step nothing hides it (~19 % of the kernel).  Each 32x32 tile is instead transposed through
+    // 4 KB of the (now free) halo buffer: 16 ds_write_b32, then 4 ds_read_b128 give every lane 4 consecutive channels of a
+    // row, and the tile leaves in 4 global_store_dwordx4 per lane (8 full 128-byte rows per instruction).  A 32-float row
+    // stride is conflict-free for both the b32 writes and the b128 lane groups.
+    const int co = co0 + ct * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
+    // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
+    const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
+    auto store_tiles = [&](auto checked) {
+        constexpr bool CHK = decltype(checked)::value;
+#pragma unroll
+        for (int i = 0; i < CV_MTW; ++i) {
+            int mt = mp + i * MPARTS;
+            if (mt < nMT) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    float v = acc[i][j] + bv;
+                    tsc[row * 32 + r] = v;
+                    bool ok = true;
+                    if (CHK) {
+                        int p = mt * 32 + row;
+                        int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                        ok = p < MROWS && t0 + tl < T && f < F;
+                    }
+                    if (ok) {
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int row = rq + 8 * k;
+                    int p = mt * 32 + row;
+                    int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                    f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                    if (!CHK || (p < MROWS && t0 + tl < T && f < F))
+                        *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+    if (interior) store_tiles(std::false_type{});
+    else store_tiles(std::true_type{});
+    if (stat) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        if (tid < 2 * WROWS) {
+            int which = tid / WROWS, c = tid - which * WROWS;
+            int cti = c >> 5, cr = c & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
+template <int NCT, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd_bf16x3_k(
+    const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft) {
+    constexpr int MPARTS = 4 / NCT;
+    constexpr int WROWS = 32 * NCT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    // LDS pitch of one halo time-row: F2 rows of CV_LD floats + CV_TPAD.  The pad makes the 16-B slot of flattened
+    // position p equal (9*p + const) mod 16 across the mel wrap-around inside a 32-row MFMA tile (F2*9 + 14 = FT*9 mod 16),
+    // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
+    const int TP = F2 * CV_LD + CV_TPAD;
+    const int HB = (TT + 2) * TP;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tb = blockIdx.x / nft, f0 = (blockIdx.x - tb * nft) * FT;
+    const int b = blockIdx.y, t0 = tb * TT, co0 = blockIdx.z * WROWS;
+    const int ct = wave % NCT, mp = wave / NCT;
+    const int MROWS = TT * FT;
+    const int nMT = (MROWS + 31) >> 5;
+    const int nchunks = Cin / CV_CIC, ncot = Cout >> 5, cot = blockIdx.z * NCT + ct;
+
+    int abase[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int p = (mp + i * MPARTS) * 32 + r;
+        if (p >= MROWS) p = MROWS - 1;
+        int tl = sed_fdiv(p, invF), f = p - tl * FT;
+        abase[i] = tl * TP + f * CV_LD + 4 * h;
+    }
+    f32x16 acc[CV_MTW];
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    f32x4 ph[CV_NH];
+    int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+#pragma unroll
+    for (int u = 0; u < CV_NH; ++u) {
+        int i = tid + u * 256;
+        int row = i >> 3, tt = sed_fdiv(row, invF2);
+        pdst[u] = (i < HR * 8) ? tt * TP + (row - tt * F2) * CV_LD + (i & 7) * 4 : -1;
+    }
+    auto fetch = [&](int cc) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            int i = tid + u * 256;
+            f32x4 v = {0, 0, 0, 0};
+            if (i < HR * 8) {
+                int row = i >> 3, q = i & 7;
+                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+                int t = t0 + tt - 1, f = f0 + ff - 1;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
+            }
+            ph[u] = v;
+        }
+    };
+    // a position's 32 channels are stored as 32 hi bf16 (64 B) followed by 32 lo bf16 (64 B): the same 128-byte row and
+    // 16-byte slot structure as the fp32 kernel (hi k-group g <-> fp32 group g, lo k-group g <-> fp32 group 2+g), so the
+    // conflict-free pitch analysis carries over
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) {
+            if (pdst[u] >= 0) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)ph[u][e]; lo[e] = (__bf16)(ph[u][e] - (float)hi[e]); }
+                const int q = (tid + u * 256) & 7;
+                float* rowp = buf + pdst[u] - 4 * q;
+                *(bf16x4*)(rowp + 2 * q) = hi;
+                *(bf16x4*)(rowp + 16 + 2 * q) = lo;
+            }
+        }
+    };
+    // bq[2g + part]: k-group g (16 channels), part 0 = hi, 1 = lo; one 1 KiB wave-load each
+    const bf16x8* wl = (const bf16x8*)wq + (size_t)cot * 128 + lane;
+    auto load_b = [&](bf16x8* bq, int cc, int tap) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                bq[2 * g + part] = wl[(((size_t)tap * nchunks + cc) * 2 + g) * ncot * 128 + part * 64];
+    };
+
+    fetch(0);
+    commit(smem);
+    bf16x8 bf[4];
+    load_b(bf, 0, 0);
+    __syncthreads();
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bool more = cc + 1 < nchunks;
+        if (more) fetch(cc + 1);
+        const float* halo = smem + (cc & 1) * HB;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            bf16x8 bn[4];
+            if (tap < 8) load_b(bn, cc, tap + 1);
+            else if (more) load_b(bn, cc + 1, 0);
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = kw * TP + kh * CV_LD;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                bf16x8 ah[CV_MTW], al[CV_MTW];
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i) {
+                    ah[i] = *(const bf16x8*)(halo + abase[i] + toff + g * 8);
+                    al[i] = *(const bf16x8*)(halo + abase[i] + toff + 16 + g * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < CV_MTW; ++i) {        // tiles past nMT read clamped rows and are never stored
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g + 1], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bf[2 * g], acc[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bf[g] = bn[g];
+        }
+        if (more) commit(smem + ((cc + 1) & 1) * HB);
+        __syncthreads();
+    }
+
+    // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
+    // directly is 80 global_store_dword per lane and tile set, 128-byte pieces: store-issue bound, and with both co-resident
+    // workgroups of a CU in lock step nothing hides it (~19 % of the kernel).  Each 32x32 tile is instead transposed through
+    // 4 KB of the (now free) halo buffer: 16 ds_write_b32, then 4 ds_read_b128 give every lane 4 consecutive channels of a
+    // row, and the tile leaves in 4 global_store_dwordx4 per lane (8 full 128-byte rows per instruction).  A 32-float row
+    // stride is conflict-free for both the b32 writes and the b128 lane groups.
+    const int co = co0 + ct * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < CV_MTW; ++i) {
+        int mt = mp + i * MPARTS;
+        if (mt < nMT) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                int p = mt * 32 + row;
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                float v = acc[i][j] + bv;
+                tsc[row * 32 + r] = v;
+                if (p < MROWS && t0 + tl < T && f < F) {
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int row = rq + 8 * k;
+                int p = mt * 32 + row;
+                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                if (p < MROWS && t0 + tl < T && f < F)
+                    *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (stat) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
+        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        __syncthreads();
+        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        if (tid < 2 * WROWS) {
+            int which = tid / WROWS, c = tid - which * WROWS;
+            int cti = c >> 5, cr = c & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
+extern "C" int sed_conv3x3_stat_rows(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+    ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
+    return p.kind >= 0 ? p.rows : 0;
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { sed_set_error("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
+}
+
+extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
+                               float* stat, int B, int Cin, int F, int T, int Cout, void* stream) {
+    return sed_conv3x3_fwd_ex(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, 0, stream);
+}
+
+extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
+                                  float* stat, int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
+    SED_REQUIRE(x && wp && y, "conv3x3_fwd: null pointer");
+    SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_fwd: unknown mode %d", mode);
+    if (Cin % 32 != 0 || Cout % 32 != 0 || x_is_nchw) mode = 0;      // pack_weights_ex made the same decision
+    SED_REQUIRE(B > 0 && Cin > 0 && F > 0 && T > 0 && Cout > 0, "conv3x3_fwd: bad shape B=%d Cin=%d F=%d T=%d Cout=%d", B, Cin, F, T, Cout);
+    ConvPlan p = conv_plan(B, Cin, F, T, Cout, x_is_nchw);
+    SED_REQUIRE(p.kind >= 0, "conv3x3_fwd: unsupported shape Cin=%d Cout=%d F=%d (need Cout%%4==0 and a tile that fits LDS)", Cin, Cout, F);
+    hipStream_t s = as_stream(stream);
+    const double npos = (double)B * T * F;
+    SedProfScope prof(p.kind == 0 ? SED_K_CONV_SMALL_FWD : SED_K_CONV_MFMA_FWD, s,
+                      p.kind == 0 ? 4.0 * npos * (Cin + Cout) : 2.0 * 9.0 * Cin * Cout * npos);
+    if (p.kind == 0 && Cin <= 4) {
+        size_t lds = (size_t)(p.TT + 2) * (F + 2) * Cin * sizeof(float), red = (size_t)2 * 256 * 4 * sizeof(float);
+        if (lds < red) lds = red;
+        dim3 grid(p.tblocks, B);
+        switch (Cin) {
+            case 1: conv3x3_small_fwd_c_k<1><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            case 2: conv3x3_small_fwd_c_k<2><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            case 3: conv3x3_small_fwd_c_k<3><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+            default: conv3x3_small_fwd_c_k<4><<<grid, 256, lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, F, T, Cout, p.TT); break;
+        }
+    } else if (p.kind == 0) {
+        SED_TRY(set_lds(conv3x3_small_fwd_k, p.lds));
+        conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+    } else {
+        dim3 grid(p.tblocks * p.nft, B, Cout / (32 * p.nct));
+        if (mode == 1) {                     // explicit opt-in: 3-term bf16-split MFMA (wp must come from pack_weights_ex(mode 1))
+            if (p.nct == 4) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<4, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            } else if (p.nct == 2) {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<2, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            } else {
+                SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<1, 2>), p.lds));
+                conv3x3_mfma_fwd_bf16x3_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            }
+        } else if ((size_t)B * T * F * Cin >= ((size_t)1 << 32)) {
+            sed_set_error("conv3x3_fwd: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernel", (size_t)B * T * F * Cin);
+            return -1;
+        } else if (p.nct == 4) {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+        } else if (p.nct == 2) {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+        } else {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
+            conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+        }
+    }
+    SED_LAUNCH_CHECK("conv3x3_fwd");
+    return 0;
+}
+
+// ───────────────────────── weight gradient ─────────────────────────
+struct WgradPlan {
+    int kind;        // 0 small, 1 mfma
+    int TT, FT, nft; // block tile: TT time rows x FT mel columns, nft mel tiles (mfma); FT == F on the small path
+    int ntiles, ngroups, tblocks;
+    size_t lds, slab_floats;
+};
+
+// bytes of the two-buffer bf16 hi/lo LDS image of conv3x3_wgrad_bf16x3_k (x pitch 64 B, dy pitch 320 B, 16-position k-steps)
+static size_t wgrad_bf16x3_lds(int TT, int FT) {
+    const size_t HR = (size_t)(TT + 2) * (FT + 2), MPAD = (size_t)((TT * FT + 15) / 16) * 16;
+    if (HR * 8 > 256 * 8 || MPAD * 32 > 256 * 14) return (size_t)1 << 30;      // the loader's item budget (WB_NX / WB_ND)
+    return 2 * (HR * 128 + MPAD * 640);
+}
+
+static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode = 0) {
+    WgradPlan p{};
+    p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
+    p.FT = F; p.nft = 1;
+    if (p.kind == 1) {
+        // TT time rows x (even) FT <= WG_FT mel columns with TT*FT <= 2*WG_FT positions, two LDS buffers (the DMA item
+        // budget of the kernel: WG_NX / WG_ND); more rows for a narrow mel axis (the mel-pooled topologies)
+        p.nft = cdiv(F, WG_FT);
+        p.FT = cdiv(F, p.nft);
+        p.FT += p.FT & 1;
+        p.TT = 2;
+        while (p.TT + 2 <= 62 && p.TT + 2 <= T + (T & 1) && (p.TT + 2) * p.FT <= 2 * WG_FT &&
+               (p.TT + 4) * (p.FT + 2) * 8 <= 256 * WG_NX)
+            p.TT += 2;
+        p.lds = (size_t)2 * ((size_t)(p.TT + 2) * (p.FT + 2) * 32 + (size_t)p.TT * p.FT * 128) * sizeof(float);
+        if (mode == 1) {           // the padded dy pitch makes the image larger than the fp32 one: fewer time rows per tile
+            p.TT = 1;
+            while (p.TT + 1 <= 62 && p.TT + 1 <= T && wgrad_bf16x3_lds(p.TT + 1, p.FT) <= 160 * 1024) p.TT += 1;
+            p.lds = wgrad_bf16x3_lds(p.TT, p.FT);
+        }
+    } else {
+        p.TT = 4;
+        if (p.TT > T) p.TT = T;
+        size_t a = (((size_t)(p.TT + 2) * (F + 2) + 3) & ~(size_t)3) * sizeof(float);
+        size_t red = (size_t)256 * 36 * sizeof(float);
+        p.lds = a + red;
+    }
+    p.tblocks = cdiv(T, p.TT);
+    p.ntiles = B * p.tblocks * p.nft;
+    // mfma: one resident block per CU at Cin=128 (grid = ngroups x Cin/32); small (HBM-bound): enough blocks to fill every CU 4x
+    const int maxg = (p.kind == 1) ? 64 : 1024;
+    p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
+    p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
+    return p;
+}
+
+extern "C" size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout) {
+    WgradPlan a = wgrad_plan(B, Cin, F, T, Cout, 0), b = wgrad_plan(B, Cin, F, T, Cout, 1);
+    size_t m = a.slab_floats > b.slab_floats ? a.slab_floats : b.slab_floats;
+    return m * sizeof(float);
+}
+
+// small: slabs [group][ci][9][Cout]
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    float* hp = smem;                               // [(TT+2)][F2] one input channel
+    float* red = smem + (((TT + 2) * F2 + 3) & ~3); // [nslots][9][Cout]
+    const int tid = threadIdx.x;
+    const int ncg = Cout >> 2, nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    for (int ci = 0; ci < Cin; ++ci) {
+        f32x4 acc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = (f32x4){0, 0, 0, 0};
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+            __syncthreads();
+            for (int i = tid; i < (TT + 2) * F2; i += 256) {
+                int tt, ff;
+                if (x_nchw) { tt = i % (TT + 2); ff = i / (TT + 2); } else { ff = i % F2; tt = i / F2; }
+                int t = t0 + tt - 1, f = ff - 1;
+                float v = 0.f;
+                if (t >= 0 && t < T && f >= 0 && f < F)
+                    v = x_nchw ? x[(((size_t)b * Cin + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * Cin + ci];
+                hp[tt * F2 + ff] = v;
+            }
+            __syncthreads();
+            if (active) {
+                for (int p = slot; p < TT * F; p += nslots) {
+                    int tl = p / F, f = p - tl * F;
+                    if (t0 + tl >= T) break;
+                    f32x4 d4 = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            acc[kh * 3 + kw] += hp[(tl + kw) * F2 + f + kh] * d4;
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *(f32x4*)(red + (slot * 9 + k) * Cout + cg * 4) = acc[k];
+        }
+        __syncthreads();
+        for (int i = tid; i < 9 * Cout; i += 256) {
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[s * 9 * Cout + i];
+            slabs[(((size_t)blockIdx.x * Cin + ci) * 9) * Cout + i] = a;
+        }
+    }
+}
+
+// small, Cin <= 4 (the first layer of the multichannel configurations): every input channel in ONE pass over dY
+// (the generic kernel above re-reads dY once per input channel), 9*CIN float4 accumulators per thread.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3x3_small_wgrad_c_k(
+    const float* __restrict__ x, int x_nchw, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int F, int T, int Cout, int TT, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    const int hn = (TT + 2) * F2 * CIN;
+    float* hp = smem;                               // [(TT+2)][F2][CIN]
+    float* red = smem + ((hn + 3) & ~3);            // [nslots][9][Cout]
+    const int tid = threadIdx.x;
+    const int ncg = Cout >> 2, nslots = 256 / ncg;
+    const int cg = tid % ncg, slot = tid / ncg;
+    const bool active = slot < nslots;
+    f32x4 acc[9 * CIN];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k) acc[k] = (f32x4){0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile / tblocks, t0 = (tile - b * tblocks) * TT;
+        __syncthreads();
+        for (int i = tid; i < hn; i += 256) {
+            int tt, ff, ci;
+            if (x_nchw) { tt = i % (TT + 2); ff = (i / (TT + 2)) % F2; ci = i / ((TT + 2) * F2); }
+            else { ci = i % CIN; ff = (i / CIN) % F2; tt = i / (CIN * F2); }
+            int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F)
+                v = x_nchw ? x[(((size_t)b * CIN + ci) * F + f) * T + t] : x[(((size_t)b * T + t) * F + f) * CIN + ci];
+            hp[(tt * F2 + ff) * CIN + ci] = v;
+        }
+        __syncthreads();
+        if (active) {
+            for (int p = slot; p < TT * F; p += nslots) {
+                int tl = p / F, f = p - tl * F;
+                if (t0 + tl >= T) break;
+                f32x4 d4 = *(const f32x4*)(dy + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float* q = hp + ((tl + kw) * F2 + f + kh) * CIN;
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) acc[(kh * 3 + kw) * CIN + ci] += q[ci] * d4;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) *(f32x4*)(red + (slot * 9 + k) * Cout + cg * 4) = acc[k * CIN + ci];
+        }
+        __syncthreads();
+        for (int i = tid; i < 9 * Cout; i += 256) {
+            float a = 0.f;
+            for (int s = 0; s < nslots; ++s) a += red[s * 9 * Cout + i];
+            slabs[(((size_t)blockIdx.x * CIN + ci) * 9) * Cout + i] = a;
+        }
+    }
+}
+
+// small reduce: dw[co][ci][tap] = sum_g slabs[g][ci][tap][co]; block = 32 outputs x 32 group slices
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_small_k(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                   int ngroups, int Cin, int Cout) {
+    __shared__ float s1[32][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int n = Cin * 9 * Cout;
+    const int i = blockIdx.x * 32 + cl;
+    float a = 0.f;
+    if (i < n)
+        for (int g = sl; g < ngroups; g += 32) a += slabs[(size_t)g * n + i];
+    s1[sl][cl] = a;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float A = 0.f;
+        for (int s = 0; s < 32; ++s) A += s1[s][cl];
+        int co = i % Cout, tap = (i / Cout) % 9, ci = i / (9 * Cout);
+        dw[((size_t)co * Cin + ci) * 9 + tap] = A;
+    }
+}
+
+// mfma: grid (ngroups, Cin/32, Cout/128); slabs [group][9][Cin][Cout]
+// D[ci][co] += X[pos+tap][ci] * dY[pos][co]: M = 32 input channels, N = 4 waves x 32 out channels, K = positions; all nine
+// taps share one dY read (9 accumulator tiles per wave); operands of k-step s+1 are read from LDS while the 9 MFMAs of
+// step s issue (explicit two-stage register pipeline, one wave per SIMD).
+// A block walks tiles of TT time rows x FT mel columns (TT*FT <= 80 positions: 2 x 40 at F = 40) through two LDS buffers; the next tile is brought in by
+// global_load_lds_dwordx4 (LDS-DMA: no VGPR staging, no commit pass, one barrier per tile) while the MFMA loop runs on
+// the current one.  The register-staged predecessor (4-row tiles, whole next tile prefetched into 112 VGPRs) ran at the
+// same 117 TFLOP/s but held 428 VGPRs and 114 KB of LDS per CU, which kept every other kernel off the CU; this one
+// holds 251 VGPRs, so the HBM-bound BatchNorm / first-block backward passes on the auxiliary stream really run beside it.
+// MT = false: one mel tile (FT >= F); MT = true: mel-tiled (any F).
+// The LDS image is lane-linear ([position][32 ci] / [position][128 co]): float4 number i of a tile goes to byte 16*i,
+// so wave w's u-th load instruction covers items u*256 + 64*w .. +63 with a wave-uniform LDS base.
+typedef __attribute__((address_space(1))) const void* sed_gptr_t;
+typedef __attribute__((address_space(3))) void* sed_lptr_t;
+
+template <bool MT>
+__global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NX = WG_NX, ND = WG_ND;
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    const int MROWS = TT * FT;
+    const int XH = HR * 32, BUF = XH + MROWS * 128;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    // per-thread, tile-invariant: element offset from the tile origin (b, t0, f0) and the halo / tile coordinates
+    //   xt = tt | ff << 6 (halo coordinates; ff huge: item past the tile), dt = tl | fl << 6 (fl huge: none)
+    int xo[NX], xt[NX], dofs[ND], dt[ND];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+        int i = tid + u * 256, row = i >> 3, q = i & 7;
+        int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+        xt[u] = (i < HR * 8) ? (tt | (ff << 6)) : (1 << 24);
+        xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + q * 4;
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+        int i = tid + u * 256, row = i >> 5, q = i & 31;
+        int tl = sed_fdiv(row, invF), fl = row - tl * FT;
+        dt[u] = (i < MROWS * 32) ? (tl | (fl << 6)) : (1 << 24);
+        dofs[u] = (tl * F + fl) * Cout + co0 + q * 4;
+    }
+    auto issue = [&](int tile, float* buf) {          // global -> LDS (DMA); padding / out-of-range items are zeroed
+        int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
+        int tb = rem / nft, f0 = MT ? (rem - tb * nft) * FT : 0, t0 = tb * TT;
+        const float* xb = x + (((size_t)b * T + t0) * F + f0) * Cin;
+        const float* db = dy + (((size_t)b * T + t0) * F + f0) * Cout;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256;
+            if (i < HR * 8) {
+                int t = t0 + (xt[u] & 63) - 1, f = f0 + (xt[u] >> 6) - 1;
+                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F)
+                    __builtin_amdgcn_global_load_lds((sed_gptr_t)(xb + xo[u]), (sed_lptr_t)(buf + (u * 256 + wave * 64) * 4), 16, 0, 0);
+                else
+                    *(f32x4*)(buf + i * 4) = (f32x4){0, 0, 0, 0};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + u * 256;
+            if (i < MROWS * 32) {
+                if (t0 + (dt[u] & 63) < T && f0 + (dt[u] >> 6) < F)
+                    __builtin_amdgcn_global_load_lds((sed_gptr_t)(db + dofs[u]), (sed_lptr_t)(buf + XH + (u * 256 + wave * 64) * 4), 16, 0, 0);
+                else
+                    *(f32x4*)(buf + XH + i * 4) = (f32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto compute = [&](const float* buf) {
+        const float* xh = buf;
+        const float* dys = buf + XH;
+        const int nfs = FT >> 1;
+        for (int tl = 0; tl < TT; ++tl) {
+            const float* xrow = xh + (tl * F2 + h) * 32 + r;
+            const float* drow = dys + (tl * FT + h) * 128 + wave * 32 + r;
+            float a0[9], a1[9], b0, b1;
+            auto ld = [&](int fs, float* a, float& bq) {
+                const float* xp = xrow + fs * 64;
+                bq = drow[fs * 256];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) a[kh * 3 + kw] = xp[(kw * F2 + kh) * 32];
+            };
+            ld(0, a0, b0);
+            int fs = 0;
+            for (; fs + 1 < nfs; fs += 2) {
+                ld(fs + 1, a1, b1);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0, acc[k], 0, 0, 0);
+                if (fs + 2 < nfs) ld(fs + 2, a0, b0);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[k], b1, acc[k], 0, 0, 0);
+            }
+            if (fs < nfs) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[k], b0, acc[k], 0, 0, 0);
+            }
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) issue(tile, smem);
+    __syncthreads();                                 // drains the DMA (vmcnt) and the zero writes
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) issue(nxt, smem + (cur ^ 1) * BUF);   // that buffer was last read before the previous barrier
+        compute(smem + cur * BUF);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            sl[((size_t)k * Cin + ci0 + row) * Cout + co0 + wave * 32 + r] = acc[k][j];
+        }
+}
+
+// ── weight gradient on the 3-term bf16 split (EXPERIMENT, mode 1 of sed_conv3x3_wgrad_ex) ──
+// dW[tap][ci][co] = sum_pos x[pos+tap][ci] dy[pos][co]: the contraction index is the POSITION, while both operands are
+// stored position-major (channels contiguous), so the k-contiguous fragments of v_mfma_f32_32x32x16_bf16 are gathered with
+// ds_read_b64_tr_b16: per 16-lane group a 4-position x 16-channel block comes back transposed (lane = channel, element =
+// position); two reads give a lane its 8 k values.  LDS image per tile: x halo [position][32 ci] bf16, hi and lo arrays with
+// a 64-byte pitch, dy [position][128 co] bf16, hi and lo arrays with a 320-byte pitch (both conflict-free for the
+// transposed reads: the 8 row/group chunks of a 32-lane half land on the 8 distinct 32-byte slots of the bank period).
+// Eight waves: 0-3 compute (wave w: co 32w..32w+31, nine tap accumulators), 4-7 load the next tile (global fp32 ->
+// hi/lo split -> LDS) while the others run the MFMA loop.  Same tiles, slabs and fixed-order slab reduction as the fp32 kernel.
+typedef __attribute__((address_space(3))) bf16x4* sed_lds_bf16x4_t;
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((sed_lds_bf16x4_t)(p0));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((sed_lds_bf16x4_t)(p1));
+    return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+#define WB_DYP 160      // dy row pitch in bf16 (320 B)
+#define WB_NX 8         // loader items (float4) per lane of the halo tile:  HR*8    <= 256*WB_NX
+#define WB_ND 14        // loader items (float4) per lane of the dY tile:    MPAD*32 <= 256*WB_ND
+template <bool MT>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16x3_k(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = FT + 2;
+    const int HR = (TT + 2) * F2;
+    const int MROWS = TT * FT;
+    const int KS = (MROWS + 15) >> 4, MPAD = KS * 16;
+    // per buffer (bf16 units): x hi [HR][32], x lo [HR][32], dy hi [MPAD][160], dy lo [MPAD][160]
+    const int XP = HR * 32, DP = MPAD * WB_DYP, BUFH = 2 * XP + 2 * DP;
+    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
+    __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+    if (wave >= 4) {
+        // ── loaders: global fp32 -> registers (one tile ahead of the LDS image, two ahead of the MFMA loop) -> (hi, lo)
+        // bf16 -> LDS.  All loads of a tile are issued back to back and only waited for one tile later. ──
+        constexpr int NX = WB_NX, ND = WB_ND;
+        const int lt = tid - 256;
+        int xo[NX], xt[NX], dofs[ND], dt[ND];            // tile-invariant item coordinates, as in the fp32 kernel
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            int i = lt + u * 256, row = i >> 3, qq = i & 7;
+            int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+            xt[u] = (i < HR * 8) ? (tt | (ff << 8)) : (1 << 24);
+            xo[u] = ((tt - 1) * F + (ff - 1)) * Cin + ci0 + qq * 4;
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            int i = lt + u * 256, row = i >> 5, qq = i & 31;
+            int tl = sed_fdiv(row, invF), fl = row - tl * FT;
+            dt[u] = (row < MROWS) ? (tl | (fl << 8)) : (1 << 24);
+            dofs[u] = (tl * F + fl) * Cout + co0 + qq * 4;
+        }
+        f32x4 rx[NX], rd[ND];
+        auto fetch = [&](int tile) {
+            int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
+            int tb = rem / nft, f0 = MT ? (rem - tb * nft) * FT : 0, t0 = tb * TT;
+            const float* xb = x + (((size_t)b * T + t0) * F + f0) * Cin;
+            const float* db = dy + (((size_t)b * T + t0) * F + f0) * Cout;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int t = t0 + (xt[u] & 255) - 1, f = f0 + (xt[u] >> 8) - 1;
+                rx[u] = (f32x4){0, 0, 0, 0};
+                if ((unsigned)t < (unsigned)T && (unsigned)f < (unsigned)F) rx[u] = *(const f32x4*)(xb + xo[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                rd[u] = (f32x4){0, 0, 0, 0};
+                if (t0 + (dt[u] & 255) < T && f0 + (dt[u] >> 8) < F) rd[u] = *(const f32x4*)(db + dofs[u]);
+            }
+        };
+        auto split_store = [&](const f32x4 v, __bf16* hi_at, __bf16* lo_at) {
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
+            *(bf16x4*)hi_at = hi;
+            *(bf16x4*)lo_at = lo;
+        };
+        auto commit = [&](__bf16* buf) {
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+                const int i = lt + u * 256;
+                if (i < HR * 8) split_store(rx[u], buf + i * 4, buf + XP + i * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < ND; ++u) {
+                const int i = lt + u * 256, at = (i >> 5) * WB_DYP + (i & 31) * 4;
+                if (i < MPAD * 32) split_store(rd[u], buf + 2 * XP + at, buf + 2 * XP + DP + at);
+            }
+        };
+        int tile = blockIdx.x, cur = 0;
+        if (tile < ntiles) { fetch(tile); commit(lds); }
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+        __syncthreads();
+        for (; tile < ntiles; tile += gridDim.x) {
+            const int nxt = tile + gridDim.x, nn = nxt + gridDim.x;
+            if (nxt < ntiles) commit(lds + (cur ^ 1) * BUFH);       // that buffer was last read before the previous barrier
+            if (nn < ntiles) fetch(nn);                             // in flight across the barrier (plain loads: no vmcnt drain)
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    // transposed-read lane roles: 16-lane group G = lane >> 4 covers channels 16*(G&1)..+15 and k half h = G >> 1;
+    // lane 4q+p of a group addresses block row q (a position), channels 4p..4p+3
+    const int G = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int h = G >> 1, cb = 16 * (G & 1) + 4 * pp;
+    auto compute = [&](const __bf16* buf) {
+        const __bf16* xh = buf;
+        const __bf16* xl = buf + XP;
+        const __bf16* dh = buf + 2 * XP + wave * 32 + cb;
+        const __bf16* dl = dh + DP;
+        for (int ks = 0; ks < KS; ++ks) {
+            // the two positions this lane addresses in this k-step (t = 0, 1): m = ks*16 + 8h + 4t + q
+            int m0 = ks * 16 + 8 * h + q, m1 = m0 + 4;
+            const bf16x8 bhi = lds_tr8(dh + m0 * WB_DYP, dh + m1 * WB_DYP);
+            const bf16x8 blo = lds_tr8(dl + m0 * WB_DYP, dl + m1 * WB_DYP);
+            if (m0 >= MROWS) m0 = MROWS - 1;                  // padded positions carry dy = 0; keep the x address in range
+            if (m1 >= MROWS) m1 = MROWS - 1;
+            const int tl0 = sed_fdiv(m0, invF), tl1 = sed_fdiv(m1, invF);
+            const int hp0 = (tl0 * F2 + (m0 - tl0 * FT)) * 32 + cb, hp1 = (tl1 * F2 + (m1 - tl1 * FT)) * 32 + cb;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int sh = (kw * F2 + kh) * 32;
+                    const bf16x8 ahi = lds_tr8(xh + hp0 + sh, xh + hp1 + sh);
+                    const bf16x8 alo = lds_tr8(xl + hp0 + sh, xl + hp1 + sh);
+                    const int k = kh * 3 + kw;
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[k], 0, 0, 0);
+                    acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[k], 0, 0, 0);
+                }
+        }
+    };
+
+    int tile = blockIdx.x, cur = 0;
+    __syncthreads();                                     // the first tile has landed
+    for (; tile < ntiles; tile += gridDim.x) {
+        compute(lds + cur * BUFH);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int r = lane & 31, hh = lane >> 5;
+    float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int row = (j & 3) + 8 * (j >> 2) + 4 * hh;
+            sl[((size_t)k * Cin + ci0 + row) * Cout + co0 + wave * 32 + r] = acc[k][j];
+        }
+}
+
+// mfma reduce: dw[co][ci][tap] = sum_g slabs[g][tap][ci][co]
+__global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float* __restrict__ dw,
+                                         int ngroups, int Cin, int Cout) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = Cin * 9 * Cout;
+    if (i >= n) return;
+    int co = i % Cout, ci = (i / Cout) % Cin, tap = i / (Cin * Cout);
+    float a = 0.f;
+#pragma unroll 8
+    for (int g = 0; g < ngroups; ++g) a += slabs[(size_t)g * n + i];
+    dw[((size_t)co * Cin + ci) * 9 + tap] = a;
+}
+
+extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                                 int B, int Cin, int F, int T, int Cout, void* stream) {
+    return sed_conv3x3_wgrad_ex(x, x_is_nchw, dy, dw, workspace, B, Cin, F, T, Cout, 0, stream);
+}
+
+extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                                    int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
+    SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
+    SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_wgrad: unknown mode %d", mode);
+    SED_REQUIRE(Cout % 4 == 0, "conv3x3_wgrad: Cout must be a multiple of 4 (got %d)", Cout);
+    WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
+    hipStream_t s = as_stream(stream);
+    float* slabs = (float*)workspace;
+    int n = Cin * 9 * Cout;
+    const double npos = (double)B * T * F;
+    SedProfScope prof(p.kind == 1 ? SED_K_CONV_MFMA_WGRAD : SED_K_CONV_SMALL_WGRAD, s,
+                      p.kind == 1 ? 2.0 * 9.0 * Cin * Cout * npos : 4.0 * npos * (Cin + Cout));
+    if (p.kind == 1 && mode == 1) {
+        dim3 grid(p.ngroups, Cin / 32, Cout / 128);
+        const size_t lds = p.lds;
+        SED_REQUIRE(lds <= 160 * 1024, "conv3x3_wgrad (bf16x3): tile %dx%d needs %zu B of LDS", p.TT, p.FT, lds);
+        if (p.nft == 1) {
+            SED_TRY(set_lds(conv3x3_wgrad_bf16x3_k<false>, lds));
+            conv3x3_wgrad_bf16x3_k<false><<<grid, 512, lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_wgrad_bf16x3_k<true>, lds));
+            conv3x3_wgrad_bf16x3_k<true><<<grid, 512, lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        }
+        SED_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
+        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    } else if (p.kind == 1) {
+        dim3 grid(p.ngroups, Cin / 32, Cout / 128);
+        if (p.nft == 1) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
+            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
+            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+        }
+        SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
+        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    } else {
+        SED_REQUIRE(256 % (Cout / 4) == 0 || Cout / 4 <= 256, "conv3x3_wgrad: unsupported Cout=%d", Cout);
+        const size_t lds_c = ((((size_t)(p.TT + 2) * (F + 2) * Cin + 3) & ~(size_t)3) + (size_t)256 * 36) * sizeof(float);
+        if (Cin == 2 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<2>, lds_c));
+            conv3x3_small_wgrad_c_k<2><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else if (Cin == 3 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<3>, lds_c));
+            conv3x3_small_wgrad_c_k<3><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else if (Cin == 4 && lds_c <= 150 * 1024) {
+            SED_TRY(set_lds(conv3x3_small_wgrad_c_k<4>, lds_c));
+            conv3x3_small_wgrad_c_k<4><<<p.ngroups, 256, lds_c, s>>>(x, x_is_nchw, dy, slabs, B, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_small_wgrad_k, p.lds));
+            conv3x3_small_wgrad_k<<<p.ngroups, 256, p.lds, s>>>(x, x_is_nchw, dy, slabs, B, Cin, F, T, Cout, p.TT, p.tblocks, p.ntiles);
+        }
+        SED_LAUNCH_CHECK("conv3x3_small_wgrad");
+        conv_wgrad_reduce_small_k<<<cdiv(n, 32), 1024, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    }
+    SED_LAUNCH_CHECK("conv3x3_wgrad_reduce");
+    return 0;
+}
