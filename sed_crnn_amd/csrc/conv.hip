@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         // prefetches, the CV_NH halo loads issued in tap 0.  (A smaller count than necessary only waits longer.)
         // Measured alternatives: one load per 8-k group spread over the tap (-4 %), nine taps fully unrolled (-2 %).
         if (last) asm volatile("s_waitcnt vmcnt(0)");
-        else if (more && tap < 2) asm volatile("s_waitcnt vmcnt(12)");      // 4 + CV_NH
+        else if (more && tap < 2) { static_assert(CV_NH == 8, "the vmcnt immediate below is 4 + CV_NH"); asm volatile("s_waitcnt vmcnt(12)"); }
         else asm volatile("s_waitcnt vmcnt(4)");
         bind(cur);
         const float* halo = smem + (cc & 1) * HB;
