@@ -106,6 +106,8 @@ int sed_bn_finalize_eval(const float* gamma, const float* beta, const float* run
 /* out = dropout(maxpool_{pool_f x pool_t}(relu(scale*y + shift))).
  * y [B][T][F][C] channels-last.  out_tcf=0: out [B][T/pt][F/pf][C];
  * out_tcf=1: out [B][T/pt][C][F/pf]  (the GRU feature order c*F'+f, sed.py:108-110).
+ * T/pt and F/pf are floor divisions like nn.MaxPool2d's (sed.py:90): a ragged tail is dropped by the pool; it still
+ * counts in the batch statistics and, in the backward, receives the statistics terms of the gradient.
  * drop_p=0 or training=0 disables dropout; the keep mask is a counter-based hash of
  * (seed, logical element index) so the backward pass regenerates it. */
 int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* shift, float* out,
