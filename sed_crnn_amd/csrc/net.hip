@@ -24,8 +24,8 @@ struct Layout {
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
-    size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, c1_ws, dgi, dgh, gru_bws, dgout[SED_MAX_GRU];
-    size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws;
+    size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, c1_ws, dgi[SED_MAX_GRU], dgh[SED_MAX_GRU], gru_bws, dgout[SED_MAX_GRU];
+    size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws, gemm_ws_aux;
     size_t total;     // floats
 };
 
@@ -126,8 +126,12 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->gradA = cv.take(ga);
         L->wgrad_ws = cv.take(max_wgrad + 64);
         L->c1_ws = cv.take(c1_ws);
-        L->dgi = cv.take(M * 6 * maxH);
-        L->dgh = cv.take(M * 6 * maxH);
+        // gate gradients per GRU layer: the weight-gradient GEMMs of layer i (auxiliary stream) still read them while the
+        // recurrence of layer i-1 writes its own on the main stream
+        for (int i = 0; i < c->n_gru; ++i) {
+            L->dgi[i] = cv.take(M * 6 * c->H[i]);
+            L->dgh[i] = cv.take(M * 6 * c->H[i]);
+        }
         L->gru_bws = cv.take(sed_gru_seq_bwd_workspace_bytes(c->B, maxH) / sizeof(float));
         for (int i = 0; i < c->n_gru; ++i) L->dgout[i] = cv.take(M * 2 * c->H[i]);
         for (int j = 0; j < c->n_dense - 1; ++j) L->dact[j] = cv.take(M * c->D[j]);
@@ -146,6 +150,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
             }
         }
         L->gemm_ws = cv.take(gw + 64);
+        L->gemm_ws_aux = training ? cv.take(gw + 64) : 0;          // split-K scratch of the GEMMs issued on the auxiliary stream
     }
     L->total = cv.off;
     return 0;
@@ -322,9 +327,11 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     // created on first use, one set per calling thread and device, so concurrent callers never share an event.
     constexpr int kMaxDev = 16;
     static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
+    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 1] = {};   // [i]: recurrence of GRU layer i done (main); [SED_MAX_GRU]: its weight gradients done (aux)
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
     hipEvent_t* ev_dg = nullptr;
     hipEvent_t* ev_bn = nullptr;
+    hipEvent_t* ev_gru = nullptr;
     if (s_aux && s_aux != s_main) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) {
@@ -333,6 +340,12 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
         ev_dg = ev_all[dev][0];
         ev_bn = ev_all[dev][1];
+        ev_gru = ev_gru_all[dev];
+        for (int i = 0; i <= SED_MAX_GRU; ++i)
+            if (!ev_gru[i] && hipEventCreateWithFlags(&ev_gru[i], hipEventDisableTiming) != hipSuccess) {
+                sed_set_error("net_backward: hipEventCreate failed");
+                return SED_EINVAL;
+            }
         for (int l = 0; l < SED_MAX_CONV; ++l)
             if (!ev_dg[l]) {
                 if (hipEventCreateWithFlags(&ev_dg[l], hipEventDisableTiming) != hipSuccess ||
@@ -369,19 +382,44 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             const float* xin = (i == 0) ? ws + L.pooled[L.n_conv - 1] : ws + L.gout[i - 1];
             float* dxin = (i == 0) ? ws + L.gradA : ws + L.dgout[i - 1];
             const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
-            float* dgi = ws + L.dgi;
-            float* dgh = ws + L.dgh;
+            float* dgi = ws + L.dgi[i];
+            float* dgh = ws + L.dgh[i];
             for (int d = 0; d < 2; ++d)
                 SED_REQUIRE(g->gru_wih[i][d] && g->gru_whh[i][d] && g->gru_bih[i][d] && g->gru_bhh[i][d],
                             "net_backward: missing gradient buffers of GRU layer %d dir %d", i, d);
             float* dbih[2] = {g->gru_bih[i][0], g->gru_bih[i][1]};
             float* dbhh[2] = {g->gru_bhh[i][0], g->gru_bhh[i][1]};
             SED_TRY(sed_gru_seq_bwd(ws + L.dgout[i], ws + L.saved[i], whh, dgi, dgh, dbih, dbhh, ws + L.gru_bws, B, L.Tp, H, stream));
-            for (int d = 0; d < 2; ++d)      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
-                SED_TRY(sed_gemm_f32_wgrad(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
-                                           g->gru_whh[i][d], H, 3 * H, H, M, ws + L.gemm_ws, stream));
+            // Critical chain: recurrence(i) -> dX(i) -> recurrence(i-1) ...  The weight gradients hang off it: with an auxiliary
+            // stream the small ones (dW_hh of every layer, dW_ih of the layers above the first) run there, beside the next
+            // data-gradient GEMM / recurrence (which leaves most CUs idle), with their own split-K scratch.
+            // (layer 0's dW_hh instead follows its dW_ih on the main stream: there it fills the wait for the top block's
+            // BatchNorm backward; beside the MFMA-bound dX GEMM it ran at a tenth of its rate and slowed that one by 18 %)
+            const bool on_aux = s_aux && i > 0;
+            void* wst = on_aux ? aux_stream : stream;
+            float* wws = ws + (on_aux ? L.gemm_ws_aux : L.gemm_ws);
+            if (on_aux) {
+                (void)hipEventRecord(ev_gru[i], s_main);
+                (void)hipStreamWaitEvent(s_aux, ev_gru[i], 0);
+            }
+            auto dw_hh = [&]() -> int {      // dW_hh = dgh^T h_prev (block-diagonal over the directions)
+                for (int d = 0; d < 2; ++d)
+                    SED_TRY(sed_gemm_f32_wgrad(dgh + d * 3 * H, 1, 6 * H, ws + L.saved[i] + ((size_t)d * 5 + 4) * H, 10 * H, 1,
+                                               g->gru_whh[i][d], H, 3 * H, H, M, wws, wst));
+                return 0;
+            };
+            if (on_aux || !s_aux) SED_TRY(dw_hh());
             const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K &&
                                g->gru_wih[i][1] == g->gru_wih[i][0] + (size_t)3 * H * K;
+            auto dw_ih = [&](void* st, float* gws) -> int {
+                if (fused)
+                    return sed_gemm_f32_wgrad(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, gws, st);
+                for (int d = 0; d < 2; ++d)
+                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, st));
+                return 0;
+            };
+            if (on_aux) SED_TRY(dw_ih(aux_stream, wws));
+            if (i == 0 && s_aux) (void)hipEventRecord(ev_gru[SED_MAX_GRU], s_aux);      // every weight gradient of the aux stream is issued
             // data gradient first: for layer 0 it is the input of the top conv block's BatchNorm backward, which then runs
             // on the auxiliary stream beside the (independent, MFMA-bound) weight-gradient GEMM
             if (fused) {                     // both directions at once: dx = dgi W_ih (K = 6H), dW_ih = dgi^T x (M = 6H)
@@ -398,13 +436,11 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, top, 3, 1.f, aux_stream));
                 (void)hipEventRecord(ev_bn[top], s_aux);
             }
-            if (fused) {
-                SED_TRY(sed_gemm_f32_wgrad(dgi, 1, 6 * H, xin, K, 1, g->gru_wih[i][0], K, 6 * H, K, M, ws + L.gemm_ws, stream));
-            } else {
-                for (int d = 0; d < 2; ++d)
-                    SED_TRY(sed_gemm_f32(dgi + d * 3 * H, 1, 6 * H, xin, K, 1, g->gru_wih[i][d], K, nullptr, 0.f, 3 * H, K, M, stream));
-            }
+            if (!on_aux) SED_TRY(dw_ih(stream, ws + L.gemm_ws));
+            if (s_aux && i == 0) SED_TRY(dw_hh());
         }
+        // the stage's gradients are complete on the main stream when it returns (the all-reduce of its bucket is issued there)
+        if (s_aux) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU], 0);
     }
     // ── conv blocks, last to first ──
     // Critical chain: dgrad(top) -> BN(top-1) -> dgrad(top-1) -> ... -> dgrad(1) -> BN(0).  The weight gradients hang off
