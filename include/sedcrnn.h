@@ -337,7 +337,10 @@ int sed_net_forward(const sed_net_cfg* cfg, const sed_net_params* p, const float
  * sed_net_backward_ready_stage(cfg, l) returns (block 0: the last stage; every other block: the stage of block 1).
  * aux_stream (NULL or == stream: serial): a second hipStream_t for the HBM-bound BatchNorm/ReLU/pool backward passes
  * that have MFMA-bound work to hide behind: BN(top) beside the GRU weight-gradient GEMM (issued by stage 0), BN(0) (for
- * a fused first block: all of block 0) beside the conv weight gradients (issued by the stage of block 1); hipEvents
+ * a fused first block: all of block 0) beside the conv weight gradients (issued by the stage of block 1); it also takes
+ * the weight gradients that have a latency- or HBM-bound pass of the data-gradient chain to run beside: the small GRU
+ * weight-gradient GEMMs of the layers above the first (beside the recurrences) and the top conv block's weight gradient
+ * (beside the BatchNorm backward of the block below it).  hipEvents
  * order the two streams and every auxiliary launch is joined back into `stream` before the last stage returns.
  * Stages must therefore be run in order with the same aux_stream for the whole backward. */
 int sed_net_backward(const sed_net_cfg* cfg, const sed_net_params* p, const sed_net_params* g,

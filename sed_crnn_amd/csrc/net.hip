@@ -24,7 +24,7 @@ struct Layout {
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
-    size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, c1_ws, dgi[SED_MAX_GRU], dgh[SED_MAX_GRU], gru_bws, dgout[SED_MAX_GRU];
+    size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, wgrad_ws_aux, c1_ws, dgi[SED_MAX_GRU], dgh[SED_MAX_GRU], gru_bws, dgout[SED_MAX_GRU];
     size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws, gemm_ws_aux;
     size_t total;     // floats
 };
@@ -125,6 +125,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         size_t ga = max_pool > M * (size_t)L->feat ? max_pool : M * (size_t)L->feat;
         L->gradA = cv.take(ga);
         L->wgrad_ws = cv.take(max_wgrad + 64);
+        L->wgrad_ws_aux = cv.take(max_wgrad + 64);
         L->c1_ws = cv.take(c1_ws);
         // gate gradients per GRU layer: the weight-gradient GEMMs of layer i (auxiliary stream) still read them while the
         // recurrence of layer i-1 writes its own on the main stream
@@ -327,7 +328,9 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     // created on first use, one set per calling thread and device, so concurrent callers never share an event.
     constexpr int kMaxDev = 16;
     static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
-    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 1] = {};   // [i]: recurrence of GRU layer i done (main); [SED_MAX_GRU]: its weight gradients done (aux)
+    // [i]: recurrence of GRU layer i done (main); [SED_MAX_GRU]: the GRU weight gradients of the aux stream done;
+    // [SED_MAX_GRU + 1]: data gradient of the top conv block issued (main); [SED_MAX_GRU + 2]: its weight gradient done (aux)
+    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 3] = {};
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
     hipEvent_t* ev_dg = nullptr;
     hipEvent_t* ev_bn = nullptr;
@@ -341,7 +344,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         ev_dg = ev_all[dev][0];
         ev_bn = ev_all[dev][1];
         ev_gru = ev_gru_all[dev];
-        for (int i = 0; i <= SED_MAX_GRU; ++i)
+        for (int i = 0; i < SED_MAX_GRU + 3; ++i)
             if (!ev_gru[i] && hipEventCreateWithFlags(&ev_gru[i], hipEventDisableTiming) != hipSuccess) {
                 sed_set_error("net_backward: hipEventCreate failed");
                 return SED_EINVAL;
@@ -461,6 +464,9 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     // an auxiliary stream it hides behind the MFMA weight gradients too instead of trailing them on the main stream
     const bool wg0_with_bn = L.n_conv > 1 && !L.cv[0].fused;
     const int top = L.n_conv - 1;
+    // the top block's weight gradient runs on the auxiliary stream (decided by the configuration alone: the stages of one
+    // backward may arrive in separate calls)
+    const bool top_wgrad_on_aux = s_aux && top > 1;
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
@@ -477,6 +483,14 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         // data gradient = the same convolution with flipped, transposed taps
         SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
         if (l > 1) {
+            if (top_wgrad_on_aux && l == top) {
+                // it starts here, beside BN(l-1) and then the next data gradient (config 2: step -65 us; started any
+                // earlier, beside dgrad(top), +80 us)
+                (void)hipEventRecord(ev_gru[SED_MAX_GRU + 1], s_main);
+                (void)hipStreamWaitEvent(s_aux, ev_gru[SED_MAX_GRU + 1], 0);
+                SED_TRY(sed_conv3x3_wgrad_ex(ws + L.pooled[l - 1], q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws_aux, B, q.Cin, q.F, q.T, q.C, c->conv_mode, aux_stream));
+                (void)hipEventRecord(ev_gru[SED_MAX_GRU + 2], s_aux);
+            }
             SED_TRY(bn_passes(l - 1, stream));
             continue;
         }
@@ -490,7 +504,11 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             SED_TRY(bn_passes(0, stream));
             if (wg0_with_bn) SED_TRY(wgrad_on(0, stream));
         }
-        for (int k = top; k >= 1; --k) SED_TRY(wgrad(k));
+        for (int k = top; k >= 1; --k) {
+            if (k == top && top_wgrad_on_aux) continue;
+            SED_TRY(wgrad(k));
+        }
+        if (top_wgrad_on_aux) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU + 2], 0);
     }
     return 0;
 }
