@@ -273,6 +273,19 @@ def run_rank(args):
     ms, n, units = C.c_double(), C.c_long(), C.c_double()
     lib.sed_prof_read(tag, C.byref(ms), C.byref(n), C.byref(units))
     lib.sed_prof_enable(0)
+    # the same kernel with the GPU to itself (outside the timed region): in the fit step one of its four launches per step
+    # (the data gradient of conv2) shares the CUs with the top block's weight gradient on the auxiliary stream, so its
+    # duration above covers part of that kernel's work too; the forward launches of a forward-only pass (same two shapes,
+    # in the same proportion) run alone
+    ms_x, n_x, units_x = C.c_double(), C.c_long(), C.c_double()
+    if rank == 0:
+        model.train()
+        lib.sed_prof_enable(1 << tag)
+        for _ in range(8):
+            model._run_forward(x, training=True)
+        torch.cuda.synchronize()
+        lib.sed_prof_read(tag, C.byref(ms_x), C.byref(n_x), C.byref(units_x))
+        lib.sed_prof_enable(0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -331,6 +344,14 @@ def run_rank(args):
                                                f"command (profiles/{rnd}): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
                                "flops_per_launch_avg": units.value / n.value}
+            if n_x.value:
+                tf_x = units_x.value / (ms_x.value * 1e-3) / 1e12
+                out["roofline"]["alone"] = {
+                    "achieved": round(tf_x, 2), "frac": round(tf_x / peak, 4), "avg_launch_ms": round(ms_x.value / n_x.value, 4),
+                    "launches": n_x.value,
+                    "note": "same kernel, same two shapes, in 8 forward-only passes after the timed region (nothing else on the GPU); "
+                            "inside the step one launch in four overlaps the top block's weight gradient (auxiliary stream), "
+                            "which lengthens that launch and shortens the step"}
         if not args.no_cpu_baseline and world == 1:              # rank 0 at N = 1 only (a reported baseline, not part of the step)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
