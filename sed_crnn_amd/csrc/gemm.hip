@@ -317,6 +317,14 @@ static GemmPlan gemm_plan(int M, int N, int K, int policy) {
         p.k_len = ((cdiv(K, 2) + GM_BK - 1) / GM_BK) * GM_BK;
         p.splits = cdiv(K, p.k_len);
     }
+    // forward projections (policy 1): two K-slices for a long K and a narrow output, decided by N and K ALONE — the same
+    // split for every batch size, so a sample's result does not depend on the batch it is evaluated in (the rule above
+    // looks at the tile count, i.e. at M, which is why it is reserved for weight gradients).  At N <= 1024 the usual
+    // batches give at most one workgroup per CU (one wave per SIMD); two co-resident slices hide each other's waits.
+    if (policy == 1 && K >= 4096 && N <= 1024) {
+        p.k_len = ((cdiv(K, 2) + GM_BK - 1) / GM_BK) * GM_BK;
+        p.splits = cdiv(K, p.k_len);
+    }
     return p;
 }
 
