@@ -64,3 +64,24 @@ def er_1sec(O, T, block):
 def compute_scores(pred, y, frames_in_1_sec=50):
     return {"f1_overall_1sec": f1_1sec(pred, y, frames_in_1_sec),
             "er_overall_1sec": er_1sec(pred, y, frames_in_1_sec)}
+
+
+def segment_counts(O, T, block):
+    """The 17 integers the device kernel hands back instead of the predictions (include/sedcrnn.h SED_SEGMENT_COUNTS), from
+    the reference's own intermediate quantities (metrics.py:20-68; confusion counts of crnn_lightning.py:115-119):
+    frame-wise TP, Nref, Nsys, S, D, I | TP, Nref, Nsys over ceil blocks | S, D, I, Nref over floor blocks | tn, fp, fn, tp."""
+    O, T = _as2d(O).astype(np.int64), _as2d(T).astype(np.int64)
+
+    def f1_counts(o, t):
+        return [int(((2 * t - o) == 1).sum()), int(t.sum()), int(o.sum())]
+
+    def er_counts(o, t):
+        fp = np.logical_and(t == 0, o == 1).sum(1)
+        fn = np.logical_and(t == 1, o == 0).sum(1)
+        return [int(np.minimum(fp, fn).sum()), int(np.maximum(0, fn - fp).sum()), int(np.maximum(0, fp - fn).sum())]
+    nc, nf = int(np.ceil(O.shape[0] / block)), int(O.shape[0] / block)
+    oc, tc = _block_max(O, block, nc).astype(np.int64), _block_max(T, block, nc).astype(np.int64)
+    of, tf = _block_max(O, block, nf).astype(np.int64), _block_max(T, block, nf).astype(np.int64)
+    cm = [int(((T == 0) & (O == 0)).sum()), int(((T == 0) & (O == 1)).sum()),
+          int(((T == 1) & (O == 0)).sum()), int(((T == 1) & (O == 1)).sum())]
+    return f1_counts(O, T) + er_counts(O, T) + f1_counts(oc, tc) + er_counts(of, tf) + [int(tf.sum())] + cm

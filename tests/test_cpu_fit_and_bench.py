@@ -180,3 +180,46 @@ def test_label_raster_and_per_recording_cache_format(tmp_path):
     np.savez(tmp_path / "bad_mon.npz", mbe, lbl[:-1])
     with pytest.raises(ValueError, match="label frames"):
         feature.load_video_npz(str(tmp_path / "bad_mon.npz"))
+
+
+# ───────────────────────── epoch scores from integer counts (host formulas, no GPU) ─────────────────────────
+@pytest.mark.parametrize("n,tp,k,block,seed", [(6, 8, 1, 5, 1234), (5, 7, 6, 4, 1), (33, 8, 1, 5, 2), (2, 3, 2, 50, 3), (16, 32, 1, 5, 4),
+                                                (1, 4, 1, 5, 5), (7, 8, 3, 8, 6)])
+def test_scores_from_counts_equal_the_reference_metrics(n, tp, k, block, seed):
+    """`metrics.scores_from_counts` applies the reference's float64 formulas (metrics.py:25-29,43-44) to the 17 integers
+    the device kernel returns; here the integers come from the oracle's numpy restatement, so the host half of the
+    device-metrics path is pinned without a GPU: all four scores and the confusion matrix, incl. a partial last block
+    (F1 keeps it, ER drops it), fewer rows than one block, and K = 6."""
+    from oracle import metrics_ref
+    from sed_crnn_amd import metrics
+    rng = np.random.default_rng(seed)
+    p = rng.random((n, tp, k)).astype(np.float32)
+    t = (rng.random((n, tp, k)) > 0.6).astype(np.float32)
+    o = p > 0.5
+    counts = metrics_ref.segment_counts(o, t, block)
+    assert len(counts) == metrics.N_COUNTS
+    got = metrics.scores_from_counts(counts)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = {"f1_overall_framewise": metrics_ref.f1_framewise(o, t), "er_overall_framewise": metrics_ref.er_framewise(o, t),
+                "f1_overall_1sec": metrics_ref.f1_1sec(o, t, block), "er_overall_1sec": metrics_ref.er_1sec(o, t, block)}
+    for key, w in want.items():
+        g = got[key]
+        assert (np.isnan(w) and np.isnan(g)) or g == w, (key, g, w)          # bit-equal float64 (nan when Nref = 0 blocks)
+    o2, t2 = o.reshape(-1, k), t.reshape(-1, k)
+    assert got["cm"].tolist() == [[int(((t2 == 0) & ~o2).sum()), int(((t2 == 0) & o2).sum())],
+                                  [int(((t2 == 1) & ~o2).sum()), int(((t2 == 1) & o2).sum())]]
+    # the host metrics module itself (the reference's API names) agrees as well
+    assert metrics.compute_scores(o, t, block) == {"f1_overall_1sec": want["f1_overall_1sec"], "er_overall_1sec": want["er_overall_1sec"]} \
+        or np.isnan(want["er_overall_1sec"])
+
+
+def test_known_answer_of_the_reference_metrics_through_the_counts():
+    """rng(1234), p > 0.5 vs t, block 5 -> f1 = 0.8888888888888887, er = 0.125 (48 rows: 10 ceil / 9 floor blocks)."""
+    from oracle import metrics_ref
+    from sed_crnn_amd import metrics
+    rng = np.random.default_rng(1234)
+    p = rng.random((6, 8, 1)).astype(np.float32)
+    t = (rng.random((6, 8, 1)) > 0.6).astype(np.float32)
+    s = metrics.scores_from_counts(metrics_ref.segment_counts(p > 0.5, t, 5))
+    assert s["f1_overall_1sec"] == 0.8888888888888887 and s["er_overall_1sec"] == 0.125
+    assert s["f1_overall_framewise"] == 0.34146341463414626 and s["er_overall_framewise"] == 1.588235294117647

@@ -126,6 +126,22 @@ def test_device_segment_counts_equal_host_metrics(data, N, Tp, K, block):
         d = sed.metrics.compute_scores_device(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), block)
         h = sed.metrics.compute_scores(p > 0.5, t, block)
     assert all(same(d[k], h[k]) for k in h)
+    # and the 17 integers themselves against the oracle's numpy restatement of the reference's intermediate quantities
+    from oracle import metrics_ref
+    ints = sed.metrics.device_counts(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), block).cpu().tolist()
+    assert ints == metrics_ref.segment_counts(p > 0.5, t, block)
+
+
+def test_device_segment_counts_on_a_long_epoch_of_windows(data):
+    """an epoch's worth of windows (3 001 x 8 rows, K = 1, block 5: blocks straddle the window boundaries, the last one is
+    partial): exact integers vs the oracle"""
+    import sed_crnn_amd as sed
+    from oracle import metrics_ref
+    rng = np.random.default_rng(77)
+    p = rng.random((3001, 8, 1)).astype(np.float32)
+    t = (rng.random((3001, 8, 1)) > 0.9).astype(np.float32)
+    ints = sed.metrics.device_counts(torch.from_numpy(p).cuda(), torch.from_numpy(t).cuda(), 5).cpu().tolist()
+    assert ints == metrics_ref.segment_counts(p > 0.5, t, 5)
 
 
 def test_device_counts_golden_and_edges(data):
