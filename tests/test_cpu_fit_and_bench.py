@@ -223,3 +223,36 @@ def test_known_answer_of_the_reference_metrics_through_the_counts():
     s = metrics.scores_from_counts(metrics_ref.segment_counts(p > 0.5, t, 5))
     assert s["f1_overall_1sec"] == 0.8888888888888887 and s["er_overall_1sec"] == 0.125
     assert s["f1_overall_framewise"] == 0.34146341463414626 and s["er_overall_framewise"] == 1.588235294117647
+
+
+# ───────────────────────── window sampler: host-side draws (sed.py:55-79, decorte_datamodule.py:39-49) ─────────────────────────
+def test_window_sampler_draws_balanced_valid_windows_and_masks():
+    """even dataset index -> a window that contains a positive frame, odd -> a window with none (sed.py:64-70); starts stay
+    inside the fold; SpecAugment offsets follow `np.random.randint(0, n - W)` (exclusive upper bound); same seed, same draws."""
+    from sed_crnn_amd import data
+    rng = np.random.default_rng(0)
+    n = 5000
+    lab = np.zeros((n, 1), np.float32)
+    for s0 in rng.integers(0, n - 10, size=12):
+        lab[s0:s0 + rng.integers(1, 9)] = 1
+    lab[0] = 1                                             # a positive at the very start and the very end of the fold
+    lab[-1] = 1
+    mel = rng.standard_normal((n, 40)).astype(np.float32)
+    ds = data.HitWindowSet(mel, lab, device="cpu", seed=5)
+    assert len(ds) == 2 * int(lab.sum())                   # sed.py:62
+    idx = np.arange(len(ds))
+    st = ds.draw_starts(idx)
+    L = data.SEQ_LEN_IN
+    assert st.min() >= 0 and st.max() <= n - L
+    pos = lab[:, 0] == 1
+    cs = np.concatenate([[0], np.cumsum(pos)])
+    npos = cs[st + L] - cs[st]
+    assert (npos[idx % 2 == 0] >= 1).all() and (npos[idx % 2 == 1] == 0).all()
+    t, f = ds.draw_masks(64)
+    assert t.shape == f.shape == (64, data.MASKS_PER_EX)
+    assert t.min() >= 0 and t.max() < L - data.TIME_MASK_W and f.min() >= 0 and f.max() < 40 - data.FREQ_MASK_W
+    ds2 = data.HitWindowSet(mel, lab, device="cpu", seed=5)
+    np.testing.assert_array_equal(ds2.draw_starts(idx), st)
+    # the clean-negative starts are exactly the windows without a positive frame
+    neg = data.find_clean_negatives(lab, L)
+    assert set(neg.tolist()) == {s1 for s1 in range(n - L + 1) if cs[s1 + L] - cs[s1] == 0}
