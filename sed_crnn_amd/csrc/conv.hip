@@ -578,39 +578,43 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd_bf16x3_k(
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
+    // staging and weight fragments as in the fp32 kernel (asm loads, hand-counted vmcnt, clamped unconditional halo loads), with
+    // the fragments TWO steps ahead in three register sets: a step is only 30 MFMAs of 32 cycles here, shorter than an L2 trip
     f32x4 ph[CV_NH];
     int pdst[CV_NH];                      // LDS float offset of each staged float4 (-1: none)
+    unsigned hoff[CV_NH];                 // element offset of each staged float4 in x, chunk 0
+    unsigned hmask = 0;                   // bit u: the float4 is inside the input (else zero padding)
 #pragma unroll
     for (int u = 0; u < CV_NH; ++u) {
         int i = tid + u * 256;
-        int row = i >> 3, tt = sed_fdiv(row, invF2);
-        pdst[u] = (i < HR * 8) ? tt * TP + (row - tt * F2) * CV_LD + (i & 7) * 4 : -1;
+        int row = i >> 3, tt = sed_fdiv(row, invF2), ff = row - tt * F2;
+        pdst[u] = (i < HR * 8) ? tt * TP + ff * CV_LD + (i & 7) * 4 : -1;
+        int t = t0 + tt - 1, f = f0 + ff - 1;
+        if (i < HR * 8 && t >= 0 && t < T && f >= 0 && f < F) hmask |= 1u << u;
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        f = f < 0 ? 0 : (f >= F ? F - 1 : f);
+        hoff[u] = (((unsigned)b * T + t) * F + f) * Cin + (i & 7) * 4;       // < 2^32 elements: checked by the host
     }
     auto fetch = [&](int cc) {
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
-            int i = tid + u * 256;
-            f32x4 v = {0, 0, 0, 0};
-            if (i < HR * 8) {
-                int row = i >> 3, q = i & 7;
-                int tt = sed_fdiv(row, invF2), ff = row - tt * F2;
-                int t = t0 + tt - 1, f = f0 + ff - 1;
-                if (t >= 0 && t < T && f >= 0 && f < F)
-                    v = *(const f32x4*)(x + (((size_t)b * T + t) * F + f) * Cin + cc * CV_CIC + q * 4);
-            }
-            ph[u] = v;
+            const float* pu = x + (size_t)hoff[u] + cc * CV_CIC;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ph[u]) : "v"(pu));
         }
     };
     // a position's 32 channels are stored as 32 hi bf16 (64 B) followed by 32 lo bf16 (64 B): the same 128-byte row and
     // 16-byte slot structure as the fp32 kernel (hi k-group g <-> fp32 group g, lo k-group g <-> fp32 group 2+g), so the
     // conflict-free pitch analysis carries over
-    auto commit = [&](float* buf) {
+    auto commit = [&](float* buf) {       // caller: the loads have retired (a vmcnt wait that covers them has been executed)
+#pragma unroll
+        for (int u = 0; u < CV_NH; ++u) asm volatile("" : "+v"(ph[u]));
 #pragma unroll
         for (int u = 0; u < CV_NH; ++u) {
             if (pdst[u] >= 0) {
+                const f32x4 v = ((hmask >> u) & 1) ? ph[u] : (f32x4){0, 0, 0, 0};
                 bf16x4 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)ph[u][e]; lo[e] = (__bf16)(ph[u][e] - (float)hi[e]); }
+                for (int e = 0; e < 4; ++e) { hi[e] = (__bf16)v[e]; lo[e] = (__bf16)(v[e] - (float)hi[e]); }
                 const int q = (tid + u * 256) & 7;
                 float* rowp = buf + pdst[u] - 4 * q;
                 *(bf16x4*)(rowp + 2 * q) = hi;
@@ -624,46 +628,75 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd_bf16x3_k(
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int part = 0; part < 2; ++part)
-                bq[2 * g + part] = wl[(((size_t)tap * nchunks + cc) * 2 + g) * ncot * 128 + part * 64];
+            for (int part = 0; part < 2; ++part) {
+                const bf16x8* pg = wl + (((size_t)tap * nchunks + cc) * 2 + g) * ncot * 128 + part * 64;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[2 * g + part]) : "v"(pg));
+            }
     };
 
     fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)");
     commit(smem);
-    bf16x8 bf[4];
-    load_b(bf, 0, 0);
+    bf16x8 bfs[3][4];
+    const int nsteps = 9 * nchunks;                       // (chunk, tap) steps, three per loop iteration (nsteps is a multiple of 9)
+    load_b(bfs[0], 0, 0);
+    load_b(bfs[1], 0, 1);                                 // nsteps >= 9
     __syncthreads();
-    for (int cc = 0; cc < nchunks; ++cc) {
+    // Step st uses the set issued two steps ago and issues the set of step st + 2.  Younger than `cur` when it is waited for: the
+    // sets of steps st + 1 and st + 2 as far as they exist (4 loads each) and, in taps 0..2 of a chunk that prefetches, the
+    // CV_NH halo loads issued in tap 0 right behind that step's set.  (A smaller count than necessary only waits longer.)
+    auto step = [&](int st, int cc, int tap, bf16x8* cur, bf16x8* nn) {
         const bool more = cc + 1 < nchunks;
-        if (more) fetch(cc + 1);
+        const int ahead = nsteps - 1 - st;                // steps after this one
+        if (ahead >= 2) {
+            int c2 = cc, t2 = tap + 2;
+            if (t2 >= 9) { t2 -= 9; ++c2; }
+            load_b(nn, c2, t2);
+        }
+        if (tap == 0 && more) fetch(cc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        static_assert(CV_NH == 8, "the vmcnt immediates below are 4*k + CV_NH");
+        if (ahead >= 2) {
+            if (more && tap < 3) asm volatile("s_waitcnt vmcnt(16)");
+            else asm volatile("s_waitcnt vmcnt(8)");
+        } else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)");
+        else asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(cur[g]));
         const float* halo = smem + (cc & 1) * HB;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            bf16x8 bn[4];
-            if (tap < 8) load_b(bn, cc, tap + 1);
-            else if (more) load_b(bn, cc + 1, 0);
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const int toff = kw * TP + kh * CV_LD;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = kw * TP + kh * CV_LD;
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                bf16x8 ah[CV_MTW], al[CV_MTW];
+        for (int g = 0; g < 2; ++g) {
+            bf16x8 ah[CV_MTW], al[CV_MTW];
 #pragma unroll
-                for (int i = 0; i < CV_MTW; ++i) {
-                    ah[i] = *(const bf16x8*)(halo + abase[i] + toff + g * 8);
-                    al[i] = *(const bf16x8*)(halo + abase[i] + toff + 16 + g * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < CV_MTW; ++i) {        // tiles past nMT read clamped rows and are never stored
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bf[2 * g + 1], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bf[2 * g], acc[i], 0, 0, 0);
-                }
+            for (int i = 0; i < CV_MTW; ++i) {
+                ah[i] = *(const bf16x8*)(halo + abase[i] + toff + g * 8);
+                al[i] = *(const bf16x8*)(halo + abase[i] + toff + 16 + g * 8);
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bf[g] = bn[g];
+            for (int i = 0; i < CV_MTW; ++i) {        // tiles past nMT read clamped rows and are never stored
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], cur[2 * g], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], cur[2 * g + 1], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], cur[2 * g], acc[i], 0, 0, 0);
+            }
         }
-        if (more) commit(smem + ((cc + 1) & 1) * HB);
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8) {
+            if (more) commit(smem + ((cc + 1) & 1) * HB);     // prefetched in tap 0: retired by the vmcnt(8) of taps 3..8
+            __syncthreads();
+        }
+    };
+    {
+        int cc = 0, tap = 0;
+#pragma unroll 1
+        for (int st = 0; st < nsteps; st += 3) {          // taps (0,1,2), (3,4,5), (6,7,8) of one chunk: the sets rotate in place
+            step(st, cc, tap, bfs[0], bfs[2]);
+            step(st + 1, cc, tap + 1, bfs[1], bfs[0]);
+            step(st + 2, cc, tap + 2, bfs[2], bfs[1]);
+            tap += 3;
+            if (tap == 9) { tap = 0; ++cc; }
+        }
     }
 
     // Epilogue.  An accumulator register holds ONE output channel per lane (32 channels x 2 rows per register), so storing it
@@ -677,37 +710,48 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd_bf16x3_k(
     float s1 = 0.f, s2 = 0.f;
     float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
     const int rq = lane >> 3, c4 = (lane & 7) * 4;
+    // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
+    const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
+    auto store_tiles = [&](auto checked) {
+        constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
-    for (int i = 0; i < CV_MTW; ++i) {
-        int mt = mp + i * MPARTS;
-        if (mt < nMT) {
+        for (int i = 0; i < CV_MTW; ++i) {
+            int mt = mp + i * MPARTS;
+            if (mt < nMT) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-                int p = mt * 32 + row;
-                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                float v = acc[i][j] + bv;
-                tsc[row * 32 + r] = v;
-                if (p < MROWS && t0 + tl < T && f < F) {
-                    s1 += v;
-                    s2 += v * v;
+                for (int j = 0; j < 16; ++j) {
+                    int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    float v = acc[i][j] + bv;
+                    tsc[row * 32 + r] = v;
+                    bool ok = true;
+                    if (CHK) {
+                        int p = mt * 32 + row;
+                        int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                        ok = p < MROWS && t0 + tl < T && f < F;
+                    }
+                    if (ok) {
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
-            __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int row = rq + 8 * k;
-                int p = mt * 32 + row;
-                int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
-                if (p < MROWS && t0 + tl < T && f < F)
-                    *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                for (int k = 0; k < 4; ++k) {
+                    int row = rq + 8 * k;
+                    int p = mt * 32 + row;
+                    int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                    f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
+                    if (!CHK || (p < MROWS && t0 + tl < T && f < F))
+                        *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
-    }
+    };
+    if (interior) store_tiles(std::false_type{});
+    else store_tiles(std::true_type{});
     if (stat) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -772,6 +816,10 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
         conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
     } else {
         dim3 grid(p.tblocks * p.nft, B, Cout / (32 * p.nct));
+        if ((size_t)B * T * F * Cin >= ((size_t)1 << 32)) {
+            sed_set_error("conv3x3_fwd: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernels", (size_t)B * T * F * Cin);
+            return -1;
+        }
         if (mode == 1) {                     // explicit opt-in: 3-term bf16-split MFMA (wp must come from pack_weights_ex(mode 1))
             if (p.nct == 4) {
                 SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<4, 2>), p.lds));
@@ -783,9 +831,6 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
                 SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<1, 2>), p.lds));
                 conv3x3_mfma_fwd_bf16x3_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
             }
-        } else if ((size_t)B * T * F * Cin >= ((size_t)1 << 32)) {
-            sed_set_error("conv3x3_fwd: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernel", (size_t)B * T * F * Cin);
-            return -1;
         } else if (p.nct == 4) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
             conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
