@@ -57,28 +57,37 @@ extern "C" int sed_window_batch(const float* mel, const float* lab, long N, int 
 }
 
 // feat [N][C*F] -> out [N/S][C][F][S] (time_last=1: the network input layout) or [N/S][C][S][F] (utils.py layout).
-__global__ __launch_bounds__(256) void pack_sequences_k(const float* __restrict__ feat, int C, int F, int S,
+// One workgroup per (sequence, channel, chunk of FC mel bins): an [S][FC] tile goes through LDS so that both the read
+// (along the mel axis) and the write (along the time axis for time_last) are contiguous; any C, F and S up to 19 000 frames.
+__global__ __launch_bounds__(256) void pack_sequences_k(const float* __restrict__ feat, int C, int F, int S, int FC,
                                                         int time_last, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];     // [S][C*F + 1]
-    const int n = blockIdx.x, tid = threadIdx.x, CF = C * F, LD = CF + 1;
-    for (int i = tid; i < S * CF; i += 256) {
-        int t = i / CF, j = i - t * CF;
-        tile[t * LD + j] = feat[((size_t)n * S + t) * CF + j];
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [S][FC + 1]
+    const int n = blockIdx.x, c = blockIdx.y, f0 = blockIdx.z * FC, tid = threadIdx.x, CF = C * F, LD = FC + 1;
+    const int fc = (F - f0 < FC) ? F - f0 : FC;
+    for (int i = tid; i < S * fc; i += 256) {
+        int t = i / fc, j = i - t * fc;
+        tile[t * LD + j] = feat[((size_t)n * S + t) * CF + c * F + f0 + j];
     }
     __syncthreads();
-    float* o = out + (size_t)n * CF * S;
-    for (int i = tid; i < CF * S; i += 256) {
-        if (time_last) { int j = i / S, t = i - j * S; o[i] = tile[t * LD + j]; }
-        else { int c = i / (S * F), r = i - c * S * F, t = r / F, f = r - t * F; o[i] = tile[t * LD + c * F + f]; }
+    float* o = out + ((size_t)n * C + c) * F * S;                     // [F][S] or [S][F] of this (sequence, channel)
+    for (int i = tid; i < S * fc; i += 256) {
+        if (time_last) { int j = i / S, t = i - j * S; o[(size_t)(f0 + j) * S + t] = tile[t * LD + j]; }
+        else { int t = i / fc, j = i - t * fc; o[(size_t)t * F + f0 + j] = tile[t * LD + j]; }
     }
 }
 
 extern "C" int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_last, float* out, void* stream) {
     SED_REQUIRE(feat && out && N >= S && C > 0 && F > 0 && S > 0, "pack_sequences: bad arguments");
-    size_t lds = (size_t)S * (C * F + 1) * sizeof(float);
-    SED_REQUIRE(lds <= 150 * 1024, "pack_sequences: sequence tile does not fit LDS");
+    SED_REQUIRE(C <= 65535 && N / S <= 0x7fffffffL, "pack_sequences: C=%d / %ld sequences exceed the grid", C, N / S);
+    int FC = (int)((size_t)(64 * 1024) / ((size_t)S * sizeof(float))) - 1;      // mel bins per tile: S*(FC+1) floats <= 64 KB
+    if (FC > F) FC = F;
+    if (FC < 1) FC = 1;
+    const size_t lds = (size_t)S * (FC + 1) * sizeof(float);
+    SED_REQUIRE(lds <= 150 * 1024, "pack_sequences: seq_len=%d too long for one LDS tile", S);
+    const int nfc = (F + FC - 1) / FC;
+    SED_REQUIRE(nfc <= 65535, "pack_sequences: too many mel chunks");
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)pack_sequences_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    pack_sequences_k<<<(unsigned)(N / S), 256, lds, as_stream(stream)>>>(feat, C, F, S, time_last, out);
+    pack_sequences_k<<<dim3((unsigned)(N / S), (unsigned)C, (unsigned)nfc), 256, lds, as_stream(stream)>>>(feat, C, F, S, FC, time_last, out);
     SED_LAUNCH_CHECK("pack_sequences");
     return 0;
 }

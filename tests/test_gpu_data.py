@@ -79,6 +79,43 @@ def test_pack_sequences_matches_utils(data):
     assert out.shape == (70 // 16, 2, 16, 40)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_pack_sequences_and_window_items_random_shapes_vs_oracle(data, seed):
+    """drawn shapes (1-6 channels, 5-128 mel bins, sequence lengths that do and do not divide the fold, windows at the fold's
+    edges, with and without SpecAugment masks): `pack_sequences` vs utils.split_in_seqs + split_multi_channels and the
+    window kernel vs `HitWindowDataset.__getitem__` + `_pool_labels` + `_spec_augment`, both as restated by the oracle
+    (pinned by goldens g7/g8), bit for bit"""
+    from oracle import data_ref
+    rng = np.random.default_rng(seed)
+    C, Fm = int(rng.integers(1, 7)), int(rng.choice([5, 13, 40, 64, 128]))
+    S = int(rng.choice([4, 16, 64, 100]))
+    N = int(rng.integers(S, 6 * S + 7))
+    feat = rng.standard_normal((N, C * Fm)).astype(np.float32)
+    want = data_ref.split_multi_channels(data_ref.split_in_seqs(feat, S), C).astype(np.float32)       # [n, C, S, F]
+    got = data.pack_sequences(torch.from_numpy(feat).cuda(), S, n_channels=C, time_last=False)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got_t = data.pack_sequences(torch.from_numpy(feat).cuda(), S, n_channels=C, time_last=True)
+    np.testing.assert_array_equal(got_t.cpu().numpy(), want.transpose(0, 1, 3, 2))
+    # window items: L a multiple of L_out, starts incl. 0 and the last legal one
+    Lo = int(rng.choice([2, 4, 8]))
+    L = Lo * int(rng.integers(1, 9))
+    n = int(rng.integers(L, 4 * L + 5))
+    mel = rng.standard_normal((n, C * Fm)).astype(np.float32)
+    lab = (rng.random((n, 1)) > 0.7).astype(np.float32)
+    ds = data.HitWindowSet(mel, lab, seq_len_in=L, seq_len_out=Lo, n_channels=C, seed=seed)
+    starts = np.array([0, n - L] + list(rng.integers(0, n - L + 1, size=6)), np.int32)
+    use_masks = bool(seed % 2) and L > data.TIME_MASK_W and Fm > data.FREQ_MASK_W
+    t = f = None
+    if use_masks:
+        t, f = ds.draw_masks(len(starts))
+    x, y = ds.gather(starts, t, f)
+    for i, st in enumerate(starts):
+        xr, yr = data_ref.window_item(mel, lab, int(st), L, Lo, tmask=None if t is None else t[i], fmask=None if f is None else f[i],
+                                      n_channels=C)
+        np.testing.assert_array_equal(x[i].cpu().numpy(), np.asarray(xr, np.float32))
+        np.testing.assert_array_equal(y[i].cpu().numpy(), np.asarray(yr, np.float32))
+
+
 def test_standard_scaler_fit_and_fused_transform(data):
     rng = np.random.default_rng(1)
     x = (rng.standard_normal((5000, 40)) * rng.uniform(0.5, 3, 40) + rng.uniform(-5, 5, 40)).astype(np.float32)
