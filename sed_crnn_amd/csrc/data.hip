@@ -98,16 +98,16 @@ extern "C" int sed_pack_sequences(const float* feat, long N, int C, int F, int S
 // rounding bound of that algorithm,  var <= N*eps*var + (N*mean*eps)^2  (_is_constant_feature), gets scale 1.
 #define CS_BLOCKS 256
 template <bool CENTRED>
-__global__ __launch_bounds__(256) void colstats_partial_k(const float* __restrict__ x, long N, int F,
+__global__ __launch_bounds__(256) void colstats_partial_k(const float* __restrict__ x, long N, int F, int ld,
                                                           const double* __restrict__ mean, double* __restrict__ part) {
-    // block handles rows [r0, r1); thread (col, slice)
+    // F <= 256 columns of a matrix with row stride ld; block handles rows [r0, r1); thread (col, slice)
     const int nsl = 256 / F > 0 ? 256 / F : 1;
     const int col = threadIdx.x % F, sl = threadIdx.x / F;
     long per = (N + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
     double a = 0.0, q = 0.0;
     const double mu = CENTRED ? mean[col] : 0.0;
     if (sl < nsl)
-        for (long r = r0 + sl; r < r1; r += nsl) { double v = (double)x[r * F + col] - mu; a += v; q += v * v; }
+        for (long r = r0 + sl; r < r1; r += nsl) { double v = (double)x[r * ld + col] - mu; a += v; q += v * v; }
     __shared__ double s1[256], s2[256];
     s1[threadIdx.x] = a; s2[threadIdx.x] = q;
     __syncthreads();
@@ -143,19 +143,24 @@ __global__ void colstats_final_k(const double* __restrict__ part, int nb, long N
 extern "C" size_t sed_col_mean_std_workspace_bytes(int F) { return ((size_t)CS_BLOCKS * 2 + 1) * F * sizeof(double); }
 
 extern "C" int sed_col_mean_std(const float* x, long N, int F, double* mean, double* stdv, void* workspace, void* stream) {
-    SED_REQUIRE(x && mean && stdv && workspace && N > 0 && F > 0 && F <= 256, "col_mean_std: bad arguments (F <= 256)");
+    SED_REQUIRE(x && mean && stdv && workspace && N > 0 && F > 0, "col_mean_std: bad arguments");
     hipStream_t s = as_stream(stream);
     int nb = N < CS_BLOCKS ? (int)N : CS_BLOCKS;
-    double* part = (double*)workspace;
-    double* mean_d = part + (size_t)CS_BLOCKS * 2 * F;
-    colstats_partial_k<false><<<nb, 256, 0, s>>>(x, N, F, nullptr, part);
-    SED_LAUNCH_CHECK("colstats_partial");
-    colstats_mean_k<<<cdiv(F, 64), 64, 0, s>>>(part, nb, N, F, mean_d);
-    SED_LAUNCH_CHECK("colstats_mean");
-    colstats_partial_k<true><<<nb, 256, 0, s>>>(x, N, F, mean_d, part);
-    SED_LAUNCH_CHECK("colstats_partial_centred");
-    colstats_final_k<<<cdiv(F, 64), 64, 0, s>>>(part, nb, N, F, mean_d, mean, stdv);
-    SED_LAUNCH_CHECK("colstats_final");
+    // wide matrices (multichannel folds: 4 x 128 = 512 columns) go through in chunks of 256 columns, each with its own
+    // slice of the workspace
+    for (int c0 = 0; c0 < F; c0 += 256) {
+        const int Fc = F - c0 < 256 ? F - c0 : 256;
+        double* part = (double*)workspace + (size_t)c0 * (CS_BLOCKS * 2 + 1);
+        double* mean_d = part + (size_t)CS_BLOCKS * 2 * Fc;
+        colstats_partial_k<false><<<nb, 256, 0, s>>>(x + c0, N, Fc, F, nullptr, part);
+        SED_LAUNCH_CHECK("colstats_partial");
+        colstats_mean_k<<<cdiv(Fc, 64), 64, 0, s>>>(part, nb, N, Fc, mean_d);
+        SED_LAUNCH_CHECK("colstats_mean");
+        colstats_partial_k<true><<<nb, 256, 0, s>>>(x + c0, N, Fc, F, mean_d, part);
+        SED_LAUNCH_CHECK("colstats_partial_centred");
+        colstats_final_k<<<cdiv(Fc, 64), 64, 0, s>>>(part, nb, N, Fc, mean_d, mean + c0, stdv + c0);
+        SED_LAUNCH_CHECK("colstats_final");
+    }
     return 0;
 }
 

@@ -116,6 +116,24 @@ def test_pack_sequences_and_window_items_random_shapes_vs_oracle(data, seed):
         np.testing.assert_array_equal(y[i].cpu().numpy(), np.asarray(yr, np.float32))
 
 
+@pytest.mark.parametrize("N,Fc", [(1, 3), (2, 40), (1000, 1), (3001, 7), (777, 240), (500, 256), (500, 257), (2000, 512), (300, 768)])
+def test_standard_scaler_any_width_vs_oracle(data, N, Fc):
+    """feature.py:127-129 on folds of any width (the multichannel configs have 4 x 128 = 512 feature columns): mean_, scale_
+    and both transforms against the oracle's restatement of sklearn (pinned by golden g9), incl. constant and huge-mean columns"""
+    from oracle import logmel_ref
+    rng = np.random.default_rng(N + Fc)
+    x = (rng.standard_normal((N, Fc)) * rng.uniform(0.1, 30, Fc) + rng.uniform(-50, 50, Fc)).astype(np.float32)
+    if Fc > 2:
+        x[:, 1] = 3.25                                            # constant column -> scale 1
+        x[:, Fc - 1] += 1e6                                       # huge mean, small spread
+    mean, scale = logmel_ref.standardize_fit(x)
+    m, sd = data.standard_scaler_fit(torch.from_numpy(x).cuda())
+    np.testing.assert_allclose(m.cpu().numpy(), mean, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(sd.cpu().numpy(), scale, rtol=1e-9)
+    out = data.standard_scaler_transform(torch.from_numpy(x).cuda(), m, sd)
+    np.testing.assert_array_equal(out.cpu().numpy(), logmel_ref.standardize_apply(x, m.cpu().numpy(), sd.cpu().numpy()))
+
+
 def test_standard_scaler_fit_and_fused_transform(data):
     rng = np.random.default_rng(1)
     x = (rng.standard_normal((5000, 40)) * rng.uniform(0.5, 3, 40) + rng.uniform(-5, 5, 40)).astype(np.float32)
