@@ -270,7 +270,7 @@ int sed_window_batch(const float* mel, const float* lab, long N, int C, int F, i
 int sed_pack_sequences(const float* feat, long N, int C, int F, int S, int time_last, float* out, void* stream);
 /* StandardScaler.fit (feature.py:127-128): per-column mean and population sigma with sklearn's rules — float64
  * accumulation, centred two-pass variance, and scale 1 for a column whose variance is within that algorithm's rounding
- * bound (sklearn's _is_constant_feature: var <= N*eps*var + (N*mean*eps)^2).  x [N][F] f32, F <= 256; mean / stdv are
+ * bound (sklearn's _is_constant_feature: var <= N*eps*var + (N*mean*eps)^2).  x [N][F] f32, any F (256-column chunks); mean / stdv are
  * FLOAT64 device arrays [F], like sklearn's mean_ / scale_ (a float32 mean would already cost 5 % of a sigma on a column
  * whose mean is 1e6 sigmas). */
 size_t sed_col_mean_std_workspace_bytes(int F);
