@@ -4,27 +4,29 @@
 // fold that stays resident in device memory.
 #include "common.h"
 
-// One workgroup per sample: gather L frames x (C*F) mel bins, transpose through LDS to the network input layout
-// x[b][c][f][t] (time contiguous), zero the SpecAugment masks, max-pool the labels.
+// One workgroup per (sample, chunk of JC feature columns): gather L frames x JC of the C*F mel bins, transpose through
+// LDS to the network input layout x[b][c][f][t] (time contiguous), zero the SpecAugment masks; the first chunk also
+// max-pools the labels.  Any window size (config 5: 512 frames x 4 x 128 bins = 1 MB per sample) goes through 64 KB tiles.
 __global__ __launch_bounds__(256) void window_batch_k(
     const float* __restrict__ mel, const float* __restrict__ lab, long N, int C, int F, int K,
     const int* __restrict__ starts, const int* __restrict__ tmask, const int* __restrict__ fmask, int M, int tw, int fw,
-    float* __restrict__ x, float* __restrict__ y, int L, int pool) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];     // [L][C*F + 1]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int CF = C * F, LD = CF + 1;
+    float* __restrict__ x, float* __restrict__ y, int L, int pool, int JC) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];     // [L][JC + 1]
+    const int b = blockIdx.x, j0 = blockIdx.y * JC, tid = threadIdx.x;
+    const int CF = C * F, LD = JC + 1;
+    const int jc = (CF - j0 < JC) ? CF - j0 : JC;
     long s0 = starts[b];
     if (s0 < 0) s0 = 0;
     if (s0 + L > N) s0 = N - L;                                        // the reference's end-of-fold fallback
-    for (int i = tid; i < L * CF; i += 256) {
-        int t = i / CF, j = i - t * CF;
-        tile[t * LD + j] = mel[(s0 + t) * CF + j];
+    for (int i = tid; i < L * jc; i += 256) {
+        int t = i / jc, j = i - t * jc;
+        tile[t * LD + j] = mel[(s0 + t) * CF + j0 + j];
     }
     __syncthreads();
-    float* xo = x + (size_t)b * CF * L;
-    for (int i = tid; i < CF * L; i += 256) {
-        int j = i / L, t = i - j * L;                                  // j = c*F + f
-        int f = j % F;
+    float* xo = x + ((size_t)b * CF + j0) * L;
+    for (int i = tid; i < jc * L; i += 256) {
+        int j = i / L, t = i - j * L;                                  // j0 + j = c*F + f
+        int f = (j0 + j) % F;
         float v = tile[t * LD + j];
         for (int m = 0; m < M; ++m) {
             int t0 = tmask ? tmask[b * M + m] : -1, f0 = fmask ? fmask[b * M + m] : -1;
@@ -32,6 +34,7 @@ __global__ __launch_bounds__(256) void window_batch_k(
         }
         xo[i] = v;
     }
+    if (blockIdx.y != 0) return;
     const int Lo = L / pool;
     for (int i = tid; i < Lo * K; i += 256) {
         int to = i / K, k = i - to * K;
@@ -47,11 +50,17 @@ extern "C" int sed_window_batch(const float* mel, const float* lab, long N, int 
     SED_REQUIRE(mel && lab && starts && x && y, "window_batch: null pointer");
     SED_REQUIRE(N >= L && C > 0 && F > 0 && K > 0 && B > 0 && L > 0 && pool > 0 && L % pool == 0, "window_batch: bad sizes");
     SED_REQUIRE(n_masks >= 0 && (n_masks == 0 || (tmask && fmask)), "window_batch: masks requested but not given");
-    size_t lds = (size_t)L * (C * F + 1) * sizeof(float);
-    SED_REQUIRE(lds <= 150 * 1024, "window_batch: window of %d x %d floats does not fit LDS", L, C * F);
+    const int CF = C * F;
+    int JC = (int)((size_t)(64 * 1024) / ((size_t)L * sizeof(float))) - 1;       // columns per tile: L*(JC+1) floats <= 64 KB
+    if (JC > CF) JC = CF;
+    if (JC < 1) JC = 1;
+    const size_t lds = (size_t)L * (JC + 1) * sizeof(float);
+    SED_REQUIRE(lds <= 150 * 1024, "window_batch: a window of %d frames is too long for one LDS tile", L);
+    const int nch = (CF + JC - 1) / JC;
+    SED_REQUIRE(nch <= 65535, "window_batch: too many column chunks");
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)window_batch_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    window_batch_k<<<B, 256, lds, as_stream(stream)>>>(mel, lab, N, C, F, K, starts, n_masks ? tmask : nullptr,
-                                                       n_masks ? fmask : nullptr, n_masks, time_w, freq_w, x, y, L, pool);
+    window_batch_k<<<dim3((unsigned)B, (unsigned)nch), 256, lds, as_stream(stream)>>>(
+        mel, lab, N, C, F, K, starts, n_masks ? tmask : nullptr, n_masks ? fmask : nullptr, n_masks, time_w, freq_w, x, y, L, pool, JC);
     SED_LAUNCH_CHECK("window_batch");
     return 0;
 }

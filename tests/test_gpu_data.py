@@ -116,6 +116,26 @@ def test_pack_sequences_and_window_items_random_shapes_vs_oracle(data, seed):
         np.testing.assert_array_equal(y[i].cpu().numpy(), np.asarray(yr, np.float32))
 
 
+def test_window_items_at_the_multichannel_configs_sizes(data):
+    """BASELINE configs 3 and 5 window shapes (256 x 2 x 40 and 512 x 4 x 128 = 1 MB per sample): gather + SpecAugment + label
+    pooling vs the oracle, bit for bit"""
+    from oracle import data_ref
+    for C, Fm, L in ((2, 40, 256), (4, 128, 512)):
+        rng = np.random.default_rng(C)
+        n = 3 * L + 11
+        mel = rng.standard_normal((n, C * Fm)).astype(np.float32)
+        lab = (rng.random((n, 1)) > 0.9).astype(np.float32)
+        ds = data.HitWindowSet(mel, lab, seq_len_in=L, seq_len_out=L // 8, n_channels=C, seed=1)
+        starts = np.array([0, n - L, 17, L + 3], np.int32)
+        t, f = ds.draw_masks(len(starts))
+        x, y = ds.gather(starts, t, f)
+        assert x.shape == (4, C, Fm, L) and y.shape == (4, L // 8, 1)
+        for i, st in enumerate(starts):
+            xr, yr = data_ref.window_item(mel, lab, int(st), L, L // 8, tmask=t[i], fmask=f[i], n_channels=C)
+            np.testing.assert_array_equal(x[i].cpu().numpy(), xr)
+            np.testing.assert_array_equal(y[i].cpu().numpy(), yr)
+
+
 @pytest.mark.parametrize("N,Fc", [(1, 3), (2, 40), (1000, 1), (3001, 7), (777, 240), (500, 256), (500, 257), (2000, 512), (300, 768)])
 def test_standard_scaler_any_width_vs_oracle(data, N, Fc):
     """feature.py:127-129 on folds of any width (the multichannel configs have 4 x 128 = 512 feature columns): mean_, scale_
