@@ -335,6 +335,22 @@ def test_logmel_vs_numpy_restatement(ops):
     np.testing.assert_allclose(out, (ref - mu) / sd, atol=2e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("n_mels", [1, 8, 64, 96, 128])
+def test_logmel_other_mel_counts_vs_numpy_restatement(ops, n_mels):
+    """filterbanks other than the fork's 40 bins (BASELINE config 5 uses 128): librosa's Slaney bank of `n_mels` bins, both
+    plans of the mel stage, against the numpy restatement (parity unpinned by the reference like the 40-bin case)"""
+    from oracle import logmel_ref
+    from sed_crnn_amd import feature
+    rng = np.random.RandomState(n_mels)
+    n = 30000
+    tt = np.arange(n) / 44100.0
+    y = (0.2 * np.sin(2 * np.pi * 700 * tt) + 0.1 * np.sin(2 * np.pi * 9000 * tt) + 0.05 * rng.randn(n)).astype(np.float32)
+    ref = logmel_ref.mbe(y, n_mels=n_mels, pad_mode="reflect")
+    out = feature.mbe(torch.from_numpy(y).cuda(), n_mels=n_mels, pad_mode="reflect").cpu().numpy()
+    assert out.shape == ref.shape == (1 + n // 1024, n_mels)
+    np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4)
+
+
 def test_logmel_edges_odd_hop_custom_bank_and_shift_invariance(ops):
     """the cold paths of the log-mel kernel and two properties that hold at any length:
     * signals shorter than one frame, an odd number of frames (the idle half wave), an odd hop (guarded loads);
