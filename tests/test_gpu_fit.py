@@ -320,3 +320,41 @@ def test_build_fold_packs_matches_the_reference_pipeline_and_feeds_the_loader(se
         np.testing.assert_allclose(got["train_x"], xtr, rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose(got["val_x"], xte, rtol=2e-6, atol=2e-6)
         assert abs(float(got["train_x"].mean())) < 1e-5 and abs(float(got["train_x"].std()) - 1.0) < 1e-3
+
+
+def test_config5_shaped_fold_trains_through_the_device_loader(sed):
+    """BASELINE config 5's data shape end to end at a small batch: a 4-channel x 128-mel fold, 512-frame windows (1 MB per sample)
+    drawn by the device sampler with SpecAugment, StandardScaler over the 512 feature columns, the C=128 / H=256 net, device-side
+    scores — every piece of the path accepts the multichannel sizes"""
+    from sed_crnn_amd import data
+    rng = np.random.default_rng(5)
+    n = 6000
+    mel = (rng.standard_normal((n, 4 * 128)) * 3 + 7).astype(np.float32)
+    lab = np.zeros((n, 1), np.float32)
+    for s0 in rng.integers(0, n - 40, size=6):
+        lab[s0:s0 + 30] = 1
+    m, sd = data.standard_scaler_fit(torch.from_numpy(mel).cuda())
+    mel_n = data.standard_scaler_transform(torch.from_numpy(mel).cuda(), m, sd).cpu().numpy()
+    assert abs(float(mel_n.mean())) < 1e-3 and abs(float(mel_n.std()) - 1) < 1e-2
+    ds = data.HitWindowSet(mel_n, lab, seq_len_in=512, seq_len_out=64, n_channels=4, augment=True, seed=3)
+    loader = data.GpuWindowLoader(ds, batch_size=4, shuffle=True, drop_last=True)
+    torch.manual_seed(0)
+    net = sed.TimePooledCRNN(conv_channels=128, dropout=0.5, in_channels=4, n_mels=128, gru_hidden=256).cuda()
+    opt = sed.FusedAdam(net.parameters(), lr=1e-3)
+    crit = sed.BCEWithLogitsLoss()
+    it = iter(loader)
+    losses = []
+    for _ in range(3):
+        x, y = next(it)
+        assert x.shape == (4, 4, 128, 512) and y.shape == (4, 64, 1)
+        opt.zero_grad()
+        loss = crit(net(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses))
+    net.eval()
+    with torch.no_grad():
+        p = torch.sigmoid(net(x))
+    sc = sed.metrics.compute_scores_device(p, y, 5)
+    assert set(sc) == {"f1_overall_1sec", "er_overall_1sec"}
