@@ -157,8 +157,24 @@ class HipCRNN(nn.Module):
 
     def _init_spec(self, *, in_channels, n_mels, conv_channels, pools, drops, gru_hidden, dense, bn_eps=1e-5,
                    bn_momentum=0.1):
-        assert len(conv_channels) == len(pools) == len(drops) <= _lib.SED_MAX_CONV
-        assert 1 <= len(gru_hidden) <= _lib.SED_MAX_GRU and 1 <= len(dense) <= _lib.SED_MAX_DENSE
+        # the kernels' structural limits, reported when the net is built rather than at its first forward
+        if not (1 <= len(conv_channels) == len(pools) == len(drops) <= _lib.SED_MAX_CONV):
+            raise ValueError(f"1..{_lib.SED_MAX_CONV} conv blocks with one pool and one dropout rate each, got "
+                             f"{len(conv_channels)}/{len(pools)}/{len(drops)}")
+        if not (1 <= len(gru_hidden) <= _lib.SED_MAX_GRU and 1 <= len(dense) <= _lib.SED_MAX_DENSE):
+            raise ValueError(f"1..{_lib.SED_MAX_GRU} GRU layers and 1..{_lib.SED_MAX_DENSE} dense layers, got "
+                             f"{len(gru_hidden)} and {len(dense)}")
+        bad = [c for c in conv_channels if c <= 0 or c % 4 or c > 1024]
+        if bad:
+            raise ValueError(f"conv channel counts must be multiples of 4 up to 1024 (float4 channel vectors), got {bad}")
+        bad = [h for h in gru_hidden if h <= 0 or h % 4 or 3 * h > 1024]
+        if bad:
+            raise ValueError(f"GRU hidden sizes must be multiples of 4 up to 340 (the recurrence keeps 3H gate columns per "
+                             f"workgroup), got {bad}")
+        if any(not (0.0 <= d < 1.0) for d in drops):
+            raise ValueError(f"dropout rates must lie in [0, 1), got {list(drops)}")
+        if in_channels < 1 or n_mels < 1 or any(pf < 1 or pt < 1 for pf, pt in pools):
+            raise ValueError("in_channels, n_mels and the pool sizes must be positive")
         self.in_channels, self.n_mels = in_channels, n_mels
         self.conv_channels = list(conv_channels)
         self.pools = [tuple(p) for p in pools]          # (pool_f, pool_t) per block

@@ -193,3 +193,19 @@ def test_model_deepcopy_and_pickle_rebuild_the_arena():
     r = torch.load(buf, weights_only=False)                     # our own file (not a reference artefact)
     assert list(r.state_dict().keys()) == list(m.state_dict().keys())
     assert all(torch.equal(a, b) for a, b in zip(r.state_dict().values(), m.state_dict().values()))
+
+
+def test_structural_limits_are_reported_at_construction():
+    """limits the reference does not have raise when the net is built (not at its first forward), with a message"""
+    import sed_crnn_amd as sed
+    with pytest.raises(ValueError, match="multiples of 4"):
+        sed.TimePooledCRNN(conv_channels=10)
+    with pytest.raises(ValueError, match="GRU hidden"):
+        sed.TimePooledCRNN(conv_channels=8, gru_hidden=30)
+    with pytest.raises(ValueError, match="GRU hidden"):
+        sed.TimePooledCRNN(conv_channels=8, gru_hidden=344)
+    with pytest.raises(ValueError, match="conv blocks"):
+        sed.TimePooledCRNN(conv_channels=8, time_pool=(2, 2, 2, 2, 2))
+    with pytest.raises(ValueError, match="dropout"):
+        sed.TimePooledCRNN(conv_channels=8, dropout=1.0)
+    sed.TimePooledCRNN(conv_channels=16, gru_hidden=340, time_pool=(2, 2, 2, 1))      # the largest legal sizes build
