@@ -253,3 +253,28 @@ def test_random_get_model_topology_vs_torch_autograd(sed, seed):
             return dict(grus[int(k.split(".")[1])].named_parameters())[k.split(".", 2)[2]].grad
         return sd[k].grad
     _grads_vs(m, want, flip, msg)
+
+
+@pytest.mark.parametrize("H,L", [(4, 2), (20, 1), (36, 3), (100, 2), (200, 1), (340, 2)])
+def test_unusual_gru_widths_vs_oracle(sed, H, L):
+    """hidden sizes off the tuned ones (32 / 128 / 256), up to the largest the recurrence kernel takes (3H <= 1024)"""
+    from oracle import crnn_ref
+    torch.manual_seed(H)
+    kw = dict(conv_channels=8, dropout=0.0, in_channels=1, n_mels=12, gru_hidden=H, gru_layers=L)
+    ref = crnn_ref.SedNetRef(**kw)
+    m = sed.TimePooledCRNN(**kw)
+    x, y = crnn_ref.synthetic_batch(3, 1, 12, 40, 5, seed=H)
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    ref.train()
+    out_r = ref(x)
+    crnn_ref.bce_logits(out_r, y).backward()
+    m.train()
+    out = m(x.cuda())
+    sed.BCEWithLogitsLoss()(out, y.cuda()).backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"H={H}")
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        if k.startswith(("gru.", "fc.")):
+            g = rg[k].grad
+            _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()), rtol=1e-2, msg=f"{k} H={H}")
