@@ -33,6 +33,7 @@ struct ConvPlan {
     int nct;        // mfma: 32-wide co tiles per block
     int tblocks;    // ceil(T/TT)
     int rows;       // stat partial rows = B * tblocks * nft
+    int nco, nci;   // small path: output channels per workgroup, input channels per launch
     size_t lds;
 };
 
@@ -82,10 +83,17 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
         if (Cout % 4 != 0) return p;
         int TT = 4;
         if (TT > T) TT = T;
-        size_t lds = ((size_t)9 * Cin * Cout + (size_t)(TT + 2) * (F + 2) * Cin) * sizeof(float);
+        // output channels per workgroup: all of them up to 64; input channels per launch: as many as fit 144 KB of LDS
+        // beside the NCO weights per input channel
+        p.nco = Cout < 64 ? Cout : 64;
+        const size_t per_ci = ((size_t)9 * p.nco + (size_t)(TT + 2) * (F + 2)) * sizeof(float);
+        size_t nci = (size_t)(144 * 1024) / per_ci;
+        if (nci < 1) return p;                          // a mel axis of > 6 000 bins
+        if (nci > (size_t)Cin) nci = Cin;
+        p.nci = (int)nci;
+        size_t lds = per_ci * nci;
         size_t red = (size_t)2 * 256 * 4 * sizeof(float);
         if (lds < red) lds = red;
-        if (lds > 150 * 1024) return p;
         p.kind = 0; p.TT = TT; p.nct = 0; p.lds = lds;
     }
     p.tblocks = cdiv(T, p.TT);
@@ -160,81 +168,89 @@ extern "C" int sed_conv3x3_pack_weights_ex(const float* w, float* wf, float* wd,
 }
 
 // ───────────────────────── small direct forward ─────────────────────────
+// Channel counts the MFMA path does not take (Cin or Cout not a multiple of 32).  A workgroup computes NCO output channels
+// (blockIdx.z) of one time block from NCI input channels [ci0, ci0 + NCI) held in LDS with their weights; wide layers run as
+// several launches over the input-channel chunks, each adding to y (first: bias, last: the statistics partials).  A fallback:
+// correct for any channel counts that are multiples of 4, not tuned.
 __global__ __launch_bounds__(256) void conv3x3_small_fwd_k(
     const float* __restrict__ x, int x_nchw, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT) {
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT,
+    int ci0, int NCI, int NCO, int first, int last) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* w_s = smem;                        // [9][Cin][Cout]
-    float* halo = smem + 9 * Cin * Cout;      // [TT+2][F+2][Cin]
+    const int co0 = blockIdx.z * NCO;
+    const int nco = (Cout - co0 < NCO) ? Cout - co0 : NCO;            // multiples of 4
+    float* w_s = smem;                        // [9][NCI][nco]
+    float* halo = smem + 9 * NCI * NCO;       // [TT+2][F+2][NCI]
     const int tid = threadIdx.x;
     const int b = blockIdx.y, t0 = blockIdx.x * TT;
     const int F2 = F + 2;
 
-    for (int i = tid; i < 9 * Cin * Cout; i += 256) {
-        int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
-        w_s[(tap * Cin + ci) * Cout + co] = wp[i];
+    for (int i = tid; i < 9 * NCI * nco; i += 256) {
+        int ci = i % NCI, co = (i / NCI) % nco, tap = i / (NCI * nco);
+        w_s[(tap * NCI + ci) * nco + co] = wp[((size_t)tap * Cout + co0 + co) * Cin + ci0 + ci];
     }
-    const int hn = (TT + 2) * F2 * Cin;
+    const int hn = (TT + 2) * F2 * NCI;
     if (x_nchw) {
         for (int i = tid; i < hn; i += 256) {         // tt fastest: time is contiguous in NCHW
             int tt = i % (TT + 2), ff = (i / (TT + 2)) % F2, ci = i / ((TT + 2) * F2);
             int t = t0 + tt - 1, f = ff - 1;
             float v = 0.f;
-            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * Cin + ci) * F + f) * T + t];
-            halo[(tt * F2 + ff) * Cin + ci] = v;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * Cin + ci0 + ci) * F + f) * T + t];
+            halo[(tt * F2 + ff) * NCI + ci] = v;
         }
     } else {
         for (int i = tid; i < hn; i += 256) {
-            int ci = i % Cin, ff = (i / Cin) % F2, tt = i / (Cin * F2);
+            int ci = i % NCI, ff = (i / NCI) % F2, tt = i / (NCI * F2);
             int t = t0 + tt - 1, f = ff - 1;
             float v = 0.f;
-            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * T + t) * F + f) * Cin + ci];
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * T + t) * F + f) * Cin + ci0 + ci];
             halo[i] = v;
         }
     }
     __syncthreads();
 
-    const int ncg = Cout >> 2;
+    const int ncg = nco >> 2;
     const int nslots = 256 / ncg;
     const int cg = tid % ncg, slot = tid / ncg;
     const bool active = slot < nslots;
     f32x4 s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0};
     if (active) {
         f32x4 bv = {0, 0, 0, 0};
-        if (bias) bv = *(const f32x4*)(bias + cg * 4);
+        if (bias && first) bv = *(const f32x4*)(bias + co0 + cg * 4);
         for (int p = slot; p < TT * F; p += nslots) {
             int tl = p / F, f = p - tl * F;
             if (t0 + tl >= T) break;
-            f32x4 acc = bv;
+            float* yp = y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + cg * 4;
+            f32x4 acc = first ? bv : *(const f32x4*)yp;
             for (int kh = 0; kh < 3; ++kh)
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * Cin;
-                    const float* wq = w_s + ((kh * 3 + kw) * Cin) * Cout + cg * 4;
-                    for (int ci = 0; ci < Cin; ++ci) {
+                    const float* hp = halo + ((tl + kw) * F2 + f + kh) * NCI;
+                    const float* wq = w_s + ((kh * 3 + kw) * NCI) * nco + cg * 4;
+                    for (int ci = 0; ci < NCI; ++ci) {
                         float xv = hp[ci];
-                        f32x4 w4 = *(const f32x4*)(wq + ci * Cout);
+                        f32x4 w4 = *(const f32x4*)(wq + ci * nco);
                         acc += xv * w4;
                     }
                 }
-            *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + cg * 4) = acc;
+            *(f32x4*)yp = acc;
             s1 += acc;
             s2 += acc * acc;
         }
     }
-    if (stat) {
+    if (stat && last) {
         __syncthreads();
-        float* red = smem;                     // [2][nslots][Cout]
+        float* red = smem;                     // [2][nslots][nco]
         if (active) {
-            *(f32x4*)(red + (slot)*Cout + cg * 4) = s1;
-            *(f32x4*)(red + (nslots + slot) * Cout + cg * 4) = s2;
+            *(f32x4*)(red + (slot)*nco + cg * 4) = s1;
+            *(f32x4*)(red + (nslots + slot) * nco + cg * 4) = s2;
         }
         __syncthreads();
         const size_t row = (size_t)b * gridDim.x + blockIdx.x;
-        for (int i = tid; i < 2 * Cout; i += 256) {
-            int which = i / Cout, co = i - which * Cout;
+        for (int i = tid; i < 2 * nco; i += 256) {
+            int which = i / nco, co = i - which * nco;
             float a = 0.f;
-            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * Cout + co];
-            stat[row * 2 * Cout + i] = a;
+            for (int s = 0; s < nslots; ++s) a += red[(which * nslots + s) * nco + co];
+            stat[row * 2 * Cout + (size_t)which * Cout + co0 + co] = a;
         }
     }
 }
@@ -813,7 +829,12 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
         }
     } else if (p.kind == 0) {
         SED_TRY(set_lds(conv3x3_small_fwd_k, p.lds));
-        conv3x3_small_fwd_k<<<dim3(p.tblocks, B), 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT);
+        const dim3 grid(p.tblocks, B, cdiv(Cout, p.nco));
+        for (int ci0 = 0; ci0 < Cin; ci0 += p.nci) {
+            const int nci = Cin - ci0 < p.nci ? Cin - ci0 : p.nci;
+            conv3x3_small_fwd_k<<<grid, 256, p.lds, s>>>(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, ci0, nci, p.nco,
+                                                         ci0 == 0, ci0 + nci >= Cin);
+        }
     } else {
         dim3 grid(p.tblocks * p.nft, B, Cout / (32 * p.nct));
         if ((size_t)B * T * F * Cin >= ((size_t)1 << 32)) {

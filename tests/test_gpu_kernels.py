@@ -35,6 +35,8 @@ CONV_CASES = [  # B, Cin, F, T, Cout, nchw
     (1, 32, 90, 9, 32, False), (1, 64, 130, 3, 64, False), (2, 128, 7, 5, 128, False), (1, 128, 40, 1, 128, False),
     # narrow mel axis of the mel-pooled topologies: tall tiles (up to 35 time rows forward, 20 in the weight gradient)
     (2, 128, 8, 44, 128, False), (1, 128, 4, 75, 128, False), (2, 128, 2, 9, 128, False), (1, 128, 8, 3, 128, False),
+    # channel counts off the MFMA path and too wide for one LDS image: the chunked fallback (several launches adding to y)
+    (2, 100, 10, 6, 100, False), (1, 36, 12, 5, 132, False), (1, 200, 8, 4, 68, False), (2, 6, 40, 5, 200, True),
 ]
 
 

@@ -278,3 +278,36 @@ def test_unusual_gru_widths_vs_oracle(sed, H, L):
         if k.startswith(("gru.", "fc.")):
             g = rg[k].grad
             _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()), rtol=1e-2, msg=f"{k} H={H}")
+
+
+@pytest.mark.parametrize("C,cin", [(4, 1), (12, 2), (20, 1), (36, 3), (100, 1), (132, 2), (256, 1), (512, 4)])
+def test_unusual_conv_widths_vs_oracle(sed, C, cin):
+    """conv channel counts that are not powers of two (fused first block falls back where its slot layout needs 256 % (C/4) == 0,
+    BatchNorm passes with partially filled thread slots), beyond one 128-channel MFMA tile group, and up to 512"""
+    from oracle import crnn_ref
+    torch.manual_seed(C)
+    kw = dict(conv_channels=C, dropout=0.0, in_channels=cin, n_mels=10, gru_hidden=8, gru_layers=1)
+    ref = crnn_ref.SedNetRef(**kw)
+    m = sed.TimePooledCRNN(**kw)
+    x, y = crnn_ref.synthetic_batch(2, cin, 10, 24, 3, seed=C)
+    x = x * 3.0
+    m.load_state_dict(ref.state_dict())
+    m.cuda()
+    ref.train()
+    bn_out = []
+    hooks = [bn.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach())) for bn in ref.bns]
+    out_r = ref(x)
+    for h in hooks:
+        h.remove()
+    flip = _deepest_flip_prone_block(bn_out, (2, 2, 2))
+    crnn_ref.bce_logits(out_r, y).backward()
+    m.train()
+    out = m(x.cuda())
+    sed.BCEWithLogitsLoss()(out, y.cuda()).backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"C={C}")
+    rg = dict(ref.named_parameters())
+    _grads_vs(m, lambda k: rg[k].grad, flip, f"C={C} cin={cin}")
+    ref.eval()
+    m.eval()
+    with torch.no_grad():
+        _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=1e-3, msg=f"eval C={C}")
