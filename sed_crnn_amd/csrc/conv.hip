@@ -919,6 +919,7 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
 }
 
 extern "C" size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout) {
+    if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0) return 0;
     WgradPlan a = wgrad_plan(B, Cin, F, T, Cout, 0), b = wgrad_plan(B, Cin, F, T, Cout, 1);
     size_t m = a.slab_floats > b.slab_floats ? a.slab_floats : b.slab_floats;
     return m * sizeof(float);

@@ -209,3 +209,32 @@ def test_structural_limits_are_reported_at_construction():
     with pytest.raises(ValueError, match="dropout"):
         sed.TimePooledCRNN(conv_channels=8, dropout=1.0)
     sed.TimePooledCRNN(conv_channels=16, gru_hidden=340, time_pool=(2, 2, 2, 1))      # the largest legal sizes build
+
+
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """robustness of the C ABI: each exported function called with NULL pointers and zero sizes returns (an error code, or 0
+    bytes/rows for the size queries) instead of faulting — argument checks come before any launch, so no GPU is needed.
+    One child process for all of them: a fault would take the child down and name the call it died in."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+from sed_crnn_amd import _lib
+L = _lib.lib()
+for name, (res, args) in _lib.SIGNATURES.items():
+    vals = []
+    for a in args:
+        if a in (C.c_float, C.c_double):
+            vals.append(a(0.0))
+        elif hasattr(a, "_type_") and isinstance(a._type_, str) and a._type_ in "iIlLqQnN":
+            vals.append(a(0))
+        else:
+            vals.append(None)
+    print("calling", name, flush=True)
+    getattr(L, name)(*vals)
+print("ALL-RETURNED")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    last = [l for l in r.stdout.splitlines() if l.startswith("calling")][-1:]
+    assert r.returncode == 0 and "ALL-RETURNED" in r.stdout, (r.returncode, last, r.stderr[-500:])
