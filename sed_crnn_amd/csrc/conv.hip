@@ -69,6 +69,7 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
     ConvPlan p{};
     p.kind = -1;
     p.FT = F; p.nft = 1;
+    if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0) return p;
     if (!x_is_nchw && Cin % CV_CIC == 0 && Cout % 32 == 0) {
         int nct = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0 ? 2 : 1);
         int mparts = 4 / nct;
@@ -884,6 +885,7 @@ static size_t wgrad_bf16x3_lds(int TT, int FT) {
 
 static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode = 0) {
     WgradPlan p{};
+    if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0) { p.kind = 0; p.TT = 1; p.FT = 1; p.nft = 1; p.tblocks = 1; return p; }
     p.kind = (!x_is_nchw && Cin % 32 == 0 && Cout % 128 == 0) ? 1 : 0;
     p.FT = F; p.nft = 1;
     if (p.kind == 1) {

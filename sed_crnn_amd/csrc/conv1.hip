@@ -397,7 +397,7 @@ static size_t c1_lds(int Cin, int F, int C, int mode) {
 }
 
 extern "C" int sed_conv1_fused_supported(int Cin, int F, int T, int C, int pool_f, int pool_t) {
-    if (Cin < 1 || Cin > 2 || C % 4 != 0 || C / 4 > 256 || (256 % (C / 4)) != 0) return 0;
+    if (Cin < 1 || Cin > 2 || C < 4 || F < 1 || T < 1 || C % 4 != 0 || C / 4 > 256 || (256 % (C / 4)) != 0) return 0;
     if (pool_t < 1 || pool_f < 1 || C1_TT % pool_t != 0 || T % C1_TT != 0 || F % pool_f != 0 || T % pool_t != 0) return 0;
     if (c1_lds(Cin, F, C, 3) > 150 * 1024) return 0;
     return 1;

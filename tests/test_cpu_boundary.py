@@ -238,3 +238,52 @@ print("ALL-RETURNED")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     last = [l for l in r.stdout.splitlines() if l.startswith("calling")][-1:]
     assert r.returncode == 0 and "ALL-RETURNED" in r.stdout, (r.returncode, last, r.stderr[-500:])
+
+
+def test_planner_entry_points_survive_random_integers():
+    """the size / shape queries (`*_workspace_bytes`, `*_rows`, `*_supported`, `sed_net_workspace_bytes`, `sed_net_out_shape`)
+    take nothing but integers (or a struct of them): seeded random values incl. zeros, negatives and INT_MAX must come back as
+    0 / an error code, never as a fault (two of them divided by a zero extent before this test existed)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, ctypes as C, random
+sys.path.insert(0, %r)
+from sed_crnn_amd import _lib
+L = _lib.lib()
+def isint(a): return hasattr(a, "_type_") and isinstance(a._type_, str) and a._type_ in "iIlLqQnN"
+r = random.Random(0)
+vals = [-7, -1, 0, 1, 2, 3, 4, 5, 7, 8, 31, 32, 33, 40, 64, 100, 127, 128, 129, 255, 256, 257, 1000, 4096, 65535, 65536, 2**20, 2**31 - 1]
+for name, (res, args) in _lib.SIGNATURES.items():
+    if not args or not all(isint(a) for a in args):
+        continue
+    print("calling", name, flush=True)
+    for it in range(400):
+        getattr(L, name)(*[t(r.choice(vals)) for t in args])
+tp, fp = C.c_int(), C.c_int()
+print("calling sed_net_workspace_bytes / sed_net_out_shape", flush=True)
+for it in range(3000):
+    cfg = _lib.NetCfg()
+    for name, typ in cfg._fields_:
+        v = getattr(cfg, name)
+        if hasattr(v, "__len__"):
+            for i in range(len(v)):
+                v[i] = r.choice([-1.0, 0.0, 0.5, 1.0, 2.0]) if isinstance(v[i], float) else r.choice(vals)
+        elif isinstance(v, float):
+            setattr(cfg, name, r.choice([-1.0, 0.0, 1e-5, 0.1, 1.0]))
+        else:
+            setattr(cfg, name, r.choice(vals))
+    if it %% 2:                                       # plausible sizes, so that the planner runs to its end
+        cfg.B, cfg.Cin, cfg.F, cfg.T = r.choice([1, 2, 16, 128]), r.choice([1, 2, 4, 6]), r.choice([5, 40, 128]), r.choice([8, 64, 256, 512])
+        cfg.n_conv, cfg.n_gru, cfg.n_dense = r.choice([1, 2, 3, 4]), r.choice([1, 2, 3]), r.choice([1, 2])
+        for i in range(4):
+            cfg.C[i] = r.choice([4, 8, 16, 100, 128, 512]); cfg.pool_f[i] = r.choice([1, 2, 5]); cfg.pool_t[i] = r.choice([1, 2, 4])
+            cfg.drop_p[i] = r.choice([0.0, 0.5]); cfg.H[i] = r.choice([4, 32, 128, 256, 340]); cfg.D[i] = r.choice([1, 6, 16])
+        cfg.conv_mode = r.choice([0, 1])
+    L.sed_net_workspace_bytes(C.byref(cfg), it & 1)
+    L.sed_net_out_shape(C.byref(cfg), C.byref(tp), C.byref(fp))
+print("ALL-RETURNED")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    last = [l for l in r.stdout.splitlines() if l.startswith("calling")][-1:]
+    assert r.returncode == 0 and "ALL-RETURNED" in r.stdout, (r.returncode, last, r.stderr[-500:])
