@@ -311,3 +311,52 @@ def test_unusual_conv_widths_vs_oracle(sed, C, cin):
     m.eval()
     with torch.no_grad():
         _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=1e-3, msg=f"eval C={C}")
+
+
+def test_many_random_topologies_run_or_refuse_cleanly(sed):
+    """120 drawn topologies (1-4 conv blocks of 4..512 channels, mixed mel/time pools, 1-6 input channels, mel widths 3..160,
+    1-3 GRU layers of 4..340 units, 1-3 dense layers, dropout on): a training forward + backward + eval forward each.  Every
+    one must either run to finite numbers or be refused with a SedHipError / ValueError that says why — never fault, hang or
+    return NaN.  (Parity is the business of the other sweeps; this one hunts launch-configuration slips.)"""
+    r = random.Random(4242)
+    ran = refused = 0
+    for it in range(120):
+        nb = r.choice([1, 2, 3, 3, 4])
+        pools = [r.choice([(1, 1), (1, 2), (2, 1), (2, 2), (5, 1), (3, 2), (1, 4)]) for _ in range(nb)]
+        pf, pt = 1, 1
+        for a, b in pools:
+            pf, pt = pf * a, pt * b
+        Fm = max(1, pf) * r.randint(1, 3) + r.randint(0, 4)
+        if r.random() < 0.2:
+            Fm = r.choice([96, 128, 160])
+        T = pt * r.randint(1, 6) + r.randint(0, pt - 1)
+        C = r.choice([4, 8, 12, 16, 32, 36, 64, 100, 128, 256, 512])
+        hid = [r.choice([4, 8, 20, 32, 128, 256, 340]) for _ in range(r.choice([1, 2, 3]))]
+        K = r.choice([1, 3, 6])
+        fc = [r.choice([2, 8, 16]) for _ in range(r.choice([0, 1, 2]))] + [K]
+        B, cin = r.choice([1, 2, 5]), r.choice([1, 2, 4, 6])
+        if B * Fm * T * C * max(cin, C) > 4e9:
+            B, T = 1, pt * 2
+        desc = f"#{it} pools={pools} F={Fm} T={T} C={C} hid={hid} fc={fc} B={B} cin={cin}"
+        try:
+            m = sed.get_model(in_channels=cin, n_mels=Fm, seq_len=T, n_classes=K, conv_channels=C, pools=pools, rnn_hidden=hid,
+                              fc=fc, dropout=0.3).cuda()
+            x = torch.randn(B, cin, Fm, T, device="cuda")
+            m.train()
+            out = m(x)
+            tp = T // pt
+            assert out.shape == (B, tp, K), desc
+            y = (torch.rand(B, tp, K, device="cuda") > 0.7).float()
+            loss = sed.BCEWithLogitsLoss()(out, y)
+            loss.backward()
+            assert bool(torch.isfinite(loss)), desc
+            for k, p in m.named_parameters():
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), (desc, k)
+            m.eval()
+            with torch.no_grad():
+                assert bool(torch.isfinite(m(x)).all()), desc
+            ran += 1
+        except (sed.SedHipError, ValueError) as e:
+            assert len(str(e)) > 20, desc              # refused with a reason
+            refused += 1
+    assert ran >= 100, (ran, refused)                   # the refusals are the LDS-sized corner cases, not the rule
