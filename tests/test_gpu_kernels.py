@@ -447,7 +447,8 @@ def test_conv3x3_bf16x3_experiment_weight_gradient(ops, B, Cin, Fm, T, Cout):
     assert torch.equal(dw, ops.conv3x3_wgrad(x.cuda(), dy.cuda(), False, mode=1).cpu())      # fixed-order reduction: run to run identical
 
 
-def test_conv3x3_forward_is_bitwise_stable_under_memory_pressure(ops):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv3x3_forward_is_bitwise_stable_under_memory_pressure(ops, mode):
     """The forward kernel prefetches weights and halo tiles from inline asm with hand-counted `s_waitcnt vmcnt`.  A count that
     is one too large reads a register before its load has landed, and whether that shows depends on memory latency: so the
     same launch is repeated while a second stream streams 1 GB copies through HBM, and every result must equal the first
@@ -457,17 +458,17 @@ def test_conv3x3_forward_is_bitwise_stable_under_memory_pressure(ops):
     x = torch.randn(B, T, Fm, Cc, device="cuda")
     w = torch.randn(Cc, Cc, 3, 3, device="cuda") / 34.0
     bias = torch.randn(Cc, device="cuda")
-    wf, _ = ops.conv3x3_pack(w)
-    y0, st0 = ops.conv3x3_fwd(x, wf, bias, False)
+    wf, _ = ops.conv3x3_pack(w, mode=mode)                # mode 1: the bf16x3 experiment kernel has the same hand-counted structure
+    y0, st0 = ops.conv3x3_fwd(x, wf, bias, False, mode=mode)
     y0, st0 = y0.clone(), st0.clone()
     ref = F.conv2d(x.permute(0, 3, 2, 1), w, bias, padding=1).permute(0, 3, 2, 1)
-    close(y0, ref, atol=3e-5, rtol=1e-4)
+    close(y0, ref, atol=3e-5 if mode == 0 else 3e-4, rtol=1e-4)
     big = torch.empty(256 << 20, device="cuda")          # 1 GiB
     side = torch.cuda.Stream()
     for it in range(24):
         with torch.cuda.stream(side):
             for _ in range(2):
                 big[: 128 << 20].copy_(big[128 << 20:], non_blocking=True)
-        y, st = ops.conv3x3_fwd(x, wf, bias, False)
+        y, st = ops.conv3x3_fwd(x, wf, bias, False, mode=mode)
         assert torch.equal(y, y0) and torch.equal(st, st0), it
     torch.cuda.synchronize()
