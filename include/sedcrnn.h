@@ -14,8 +14,12 @@
  *     allocates or frees device memory and keeps no pointer past return;
  *   - every launch is asynchronous on the hipStream_t passed as `stream`
  *     (void*; NULL = the default stream); no entry synchronises the device and the entries are
- *     re-entrant (no mutable process state) — with ONE exception, the measurement-only
- *     sed_prof_* group at the end of this header, which is off by default;
+ *     re-entrant (no mutable process state) — with TWO exceptions: the measurement-only
+ *     sed_prof_* group at the end of this header, which is off by default, and a per-thread,
+ *     per-device cache of hipEvent_t host objects (at most 15 per calling thread and device,
+ *     timing disabled) that sed_net_backward creates on its first call WITH an aux_stream to order
+ *     the two streams; they hold no device memory, are never shared between threads, and live
+ *     until the process exits (a caller that passes aux_stream = NULL never creates them);
  *   - return value: 0 = ok, <0 = argument / shape error, >0 = hipError_t.  The message
  *     of the last failure on the calling thread is sed_last_error_string().
  *

@@ -95,6 +95,28 @@ def bce_logits(logits, targets):
     return F.binary_cross_entropy_with_logits(logits, targets)
 
 
+def forward_with_masks(model, x, masks):
+    """SedNetRef.forward (sed.py:106-112) with the Bernoulli draw of nn.Dropout replaced by GIVEN keep-masks
+    (one [B,C,F,T_l/p] tensor of {0, 1/(1-p)} per conv block): two implementations with different random number
+    generators can then be compared in training mode with dropout ACTIVE.  The model's own nn.Dropout must be p = 0."""
+    for conv, bn, p, mk in zip(model.convs, model.bns, model.time_pool, masks):
+        x = F.max_pool2d(torch.relu(bn(conv(x))), (1, p)) * mk
+    b, c, f, t = x.shape
+    x, _ = model.gru(x.permute(0, 3, 1, 2).reshape(b, t, c * f))
+    return model.fc(x)
+
+
+def fit_step_with_masks(model, optimizer, x, y, masks, loss_fn=bce_logits):
+    """fit_step (sed.py:134-137) through forward_with_masks"""
+    model.train()
+    optimizer.zero_grad()
+    out = forward_with_masks(model, x, masks)
+    loss = loss_fn(out, y)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), out.detach()
+
+
 def fit_step(model, optimizer, x, y, loss_fn=bce_logits, clip_norm=None):
     """One reference fit step (sed.py:134-137; grad clip from train_lightning.py:50)."""
     model.train()
