@@ -371,6 +371,18 @@ int sed_net_backward_phases(const sed_net_cfg* cfg, const sed_net_params* p, con
                             const float* x, const float* dlogits, void* workspace, uint64_t seed,
                             int phase_begin, int phase_end, float count_scale, void* stream);
 
+/* Where an intermediate of the plan lives inside `workspace` (offsets are a pure function of cfg and `training`), for hosts
+ * that read activations and for parity tests of intermediates.  name / index:
+ *   "conv_out"[l] conv output of block l, channels-last [B][T_l][F_l][C] (absent for a recomputed first block);
+ *   "pooled"[l] block output [B][T_l/pt][F_l/pf][C] (last block: [B][T'][C][F'], the GRU feature order);
+ *   "mean" / "rstd" / "scale" / "shift"[l] the batch statistics and fused BatchNorm coefficients of block l ([C]);
+ *   "gi"[i] / "gru_out"[i] input projections [M][2][3H] and outputs [M][2H] of GRU layer i;
+ *   training only: "dconv"[l] gradient of block l's conv output, "dgru_out"[i], "grad_act"[0] the buffer that carries the
+ *   gradient of the pooled output being back-propagated (reused from block to block), "bn_sums_bwd"[0] (sum g, sum g*xhat).
+ * <0: unknown name / index for this plan. */
+int sed_net_workspace_region(const sed_net_cfg* cfg, int training, const char* name, int index,
+                             size_t* offset_bytes, size_t* n_floats);
+
 /* ───────────── in-library kernel timers — MEASUREMENT ONLY, off by default ─────────────
  * The one exception to the conventions at the top of this header: this group keeps process-wide mutable state (the
  * enabled mask and the recorded event pairs, guarded by a mutex) and sed_prof_read SYNCHRONISES (hipEventSynchronize

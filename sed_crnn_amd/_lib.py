@@ -111,6 +111,7 @@ SIGNATURES = {
     "sed_net_workspace_bytes": (_sz, [C.POINTER(NetCfg), _i]),
     "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _fp, _stream]),
     "sed_net_sync_region": (_i, [C.POINTER(NetCfg), _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "sed_net_workspace_region": (_i, [C.POINTER(NetCfg), _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "sed_net_forward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _i, _i, _f, _stream]),
     "sed_net_backward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _f, _stream]),
     "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _fp, _i, _i, _stream, _stream]),

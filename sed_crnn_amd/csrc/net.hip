@@ -281,6 +281,52 @@ extern "C" int sed_net_sync_region(const sed_net_cfg* c, int backward, int block
     return 0;
 }
 
+// Where an intermediate of the plan lives in the caller's workspace (a pure function of the config): lets a host read
+// activations (feature maps for inspection) and lets the parity tests compare intermediates, not only end results.
+extern "C" int sed_net_workspace_region(const sed_net_cfg* c, int training, const char* name, int index,
+                                        size_t* offset_bytes, size_t* n_floats) {
+    Layout L;
+    SED_TRY(build_layout(c, training, &L));
+    SED_REQUIRE(name && offset_bytes && n_floats, "net_workspace_region: null pointer");
+    const bool conv_idx = index >= 0 && index < L.n_conv, gru_idx = index >= 0 && index < L.n_gru;
+    size_t off = 0, n = 0;
+    bool ok = false;
+    auto is = [&](const char* q) { return strcmp(name, q) == 0; };
+    if (conv_idx) {
+        const ConvL& q = L.cv[index];
+        const size_t nout = (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
+        if (is("conv_out") && !q.fused) { off = L.conv_out[index]; n = nout; ok = true; }
+        else if (is("pooled")) { off = L.pooled[index]; n = npool; ok = true; }
+        else if (is("mean")) { off = L.mean[index]; n = q.C; ok = true; }
+        else if (is("rstd")) { off = L.rstd[index]; n = q.C; ok = true; }
+        else if (is("scale")) { off = L.scale[index]; n = q.C; ok = true; }
+        else if (is("shift")) { off = L.shift[index]; n = q.C; ok = true; }
+        else if (is("dconv") && training && !q.fused) { off = L.dconv[index]; n = nout; ok = true; }
+    }
+    if (!ok && gru_idx) {
+        const size_t M = (size_t)L.M, H = L.gr[index].H;
+        if (is("gi")) { off = L.gi[index]; n = M * 6 * H; ok = true; }
+        else if (is("gru_out")) { off = L.gout[index]; n = M * 2 * H; ok = true; }
+        else if (is("dgru_out") && training) { off = L.dgout[index]; n = M * 2 * H; ok = true; }
+    }
+    if (!ok && training && index == 0) {
+        if (is("grad_act")) {           // the gradient w.r.t. the pooled output currently being back-propagated (reused per block)
+            off = L.gradA;
+            size_t mp = 0;
+            for (int l = 0; l < L.n_conv; ++l) {
+                const size_t np = (size_t)c->B * L.cv[l].Tp * L.cv[l].Fp * L.cv[l].C;
+                if (np > mp) mp = np;
+            }
+            n = mp > (size_t)L.M * L.feat ? mp : (size_t)L.M * L.feat;
+            ok = true;
+        } else if (is("bn_sums_bwd")) { off = L.sum_g; n = 2 * (size_t)L.cv[0].C; ok = true; }
+    }
+    SED_REQUIRE(ok, "net_workspace_region: no region '%s'[%d] in this plan (training=%d)", name, index, training);
+    *offset_bytes = off * sizeof(float);
+    *n_floats = n;
+    return 0;
+}
+
 // BatchNorm/ReLU/pool/dropout backward of block l on stream `st` (for the fused first block: everything of block 0).
 // part 1 = reduction pass (sum g, sum g*xhat -> ws.sum_g[0..2C), dgamma, dbeta), part 2 = apply pass (dconv[l] + conv-bias
 // gradient; fused block: + weight gradient), 3 = both.  count_scale > 1: the sums were all-reduced over that many ranks.

@@ -441,6 +441,18 @@ class HipCRNN(nn.Module):
         check(lib().sed_net_sync_region(C.byref(cfg), int(backward), block, C.byref(off), C.byref(n)), "sed_net_sync_region")
         dist.all_reduce(ws[off.value // 4: off.value // 4 + n.value], op=dist.ReduceOp.SUM, group=self._sync_group)
 
+    def workspace_view(self, name, index=0):
+        """A view of an intermediate of the LAST training forward / backward inside the plan's workspace
+        (``sed_net_workspace_region``: "conv_out", "pooled", "mean", "rstd", "scale", "shift", "dconv", "gi", "gru_out",
+        "dgru_out", "grad_act", "bn_sums_bwd").  Flat fp32; valid until the next forward of that shape."""
+        if self._last is None:
+            raise RuntimeError("sed_crnn_amd: no training forward to look into")
+        cfg, ws, _ = self._last
+        off, n = C.c_size_t(), C.c_size_t()
+        check(lib().sed_net_workspace_region(C.byref(cfg), 1, name.encode(), int(index), C.byref(off), C.byref(n)),
+              "sed_net_workspace_region")
+        return ws[off.value // 4: off.value // 4 + n.value]
+
     # ── raw plan calls (also used by the fused trainer) ──
     def _run_forward(self, x, training, step_state=None):
         """step_state: optional device tensor {dropout salt, optimiser step} (uint64[2]) read by the kernels instead of a

@@ -32,6 +32,10 @@ class FusedTrainStep:
         self.graph = bool(graph) and self.reducer is None
         self._graphs = {}
         self._state = torch.zeros(2, dtype=torch.int64, device=p.device) if self.graph else None
+        # measurement aid (bench.py): with time_allreduce set, every data-parallel step brackets reducer.wait_all() with two
+        # events on the compute stream; their distance is the part of the gradient all-reduce that the backward did NOT hide
+        self.time_allreduce = False
+        self.allreduce_events = []
 
     def step(self, x, y):
         """x [B,Cin,F,T], y [B,T',K] on the device -> (loss [1], probs [B,T',K]) device tensors (no sync)."""
@@ -81,7 +85,14 @@ class FusedTrainStep:
             for s in range(nstage):
                 m._run_backward(x, dlogits, s, s + 1)
                 self.reducer.launch(s)                     # async all-reduce(avg) of this stage's arena slice
-            self.reducer.wait_all()
+            if self.time_allreduce and x.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()                                # the backward kernels of this rank are done here
+                self.reducer.wait_all()
+                e1.record()                                # ... and here every slice has arrived
+                self.allreduce_events.append((e0, e1))
+            else:
+                self.reducer.wait_all()
         g = m.flat_grads()
         coef = ops.grad_norm_clip_coef(g, self.clip_norm)[1:2] if self.clip_norm else None
         self.t += 1

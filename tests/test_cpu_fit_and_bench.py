@@ -31,6 +31,23 @@ def test_bench_gpus2_starts_two_rank_processes_itself_over_gloo():
     assert out["allreduce_avg_ok"] is True and out["params_in_sync"] is True and out["backend"] == "gloo"
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus8_plumbing_rendezvous_and_bucket_slicing_at_the_scale_run_size():
+    """the driver's SCALE run is N = 8: the launcher, the 127.0.0.1 rendezvous of 8 ranks, the parameter broadcast and the
+    staged all-reduce of every arena slice (average over 8 ranks of rank-dependent fills) at that world size, on CPU (gloo)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"                              # 8 rank processes on the build container's 8 CPUs
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0",
+                        "--plumbing-only"], capture_output=True, text=True, env=env, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["backend"] == "gloo"
+    assert out["metric"] == "plumbing-only" and out["value"] is None
+    assert out["allreduce_avg_ok"] is True and out["params_in_sync"] is True
+
+
 def test_bench_refuses_a_world_size_that_contradicts_the_flag():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--steps", "1"],

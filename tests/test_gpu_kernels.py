@@ -136,6 +136,46 @@ def test_conv1_fused_block_vs_torch(ops, B, Cin, Fm, T, Cc, pf, pt):
     assert float(db.abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("cin,mu,sd", [(1, 0.0, 1.0), (1, -3.0, 3.0), (2, 3.0, 3.0), (1, 30.0, 1.0)])
+def test_conv1_stats_from_input_moments_vs_float64_sums(ops, cin, mu, sd):
+    """round-2 advisor: the first block's batch statistics come from the Gram matrix of the shifted inputs (fp32 per
+    workgroup, fp64 across) and a fp64 quadratic form, i.e. E[y^2] - mean^2 — which cancels when the input is NOT standardised
+    (raw log-mel energies: mean and sigma of a few units).  Against float64 sums of the float64 convolution, at config-1 size:
+    the mean within 1e-6 * sqrt(E[y^2]) and the variance within 1e-5 * E[y^2] — relative to the SECOND MOMENT, which is what
+    any fp32 sum-of-squares statistic (the conv epilogue's partials included) can promise — and, for inputs up to mean = sigma
+    = 3, the resulting 1/sigma within 1e-4 relative, far inside the 1e-3 budget of the probabilities."""
+    from sed_crnn_amd._lib import lib, check, ptr, stream_ptr
+    B, Fm, T, Cc = 16, 40, 256, 128
+    gen = torch.Generator().manual_seed(int(abs(mu) * 10 + sd + cin))
+    x = torch.randn(B, cin, Fm, T, generator=gen) * sd + mu
+    w = torch.randn(Cc, cin, 3, 3, generator=gen) / np.sqrt(9 * cin)
+    b = torch.randn(Cc, generator=gen)
+    y64 = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    n = B * Fm * T
+    m64 = y64.mean((0, 2, 3))
+    q64 = (y64 ** 2).mean((0, 2, 3))
+    v64 = y64.var((0, 2, 3), unbiased=False)
+    L = lib()
+    assert L.sed_conv1_fused_supported(cin, Fm, T, Cc, 1, 2)
+    wf, _ = ops.conv3x3_pack(g(w))
+    stat = torch.empty(1, 2, Cc, device="cuda")
+    ws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, cin, T) // 4 + 1, device="cuda")
+    xg = g(x)
+    check(L.sed_conv1_stats(ptr(xg), ptr(wf), ptr(g(b)), ptr(stat), ptr(ws), B, cin, Fm, T, Cc, stream_ptr()), "conv1_stats")
+    rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
+    mean, rstd, _, _ = ops.bn_finalize_train(stat, n, torch.ones(Cc).cuda(), torch.zeros(Cc).cuda(), rm, rv)
+    mean, rstd = mean.cpu().double(), rstd.cpu().double()
+    var = 1.0 / rstd ** 2 - 1e-5
+    e_m = float(((mean - m64).abs() / q64.sqrt()).max())
+    e_v = float(((var - v64).abs() / q64).max())
+    e_r = float((rstd * (v64 + 1e-5).sqrt() - 1.0).abs().max())
+    print(f"conv1_stats cin={cin} input N({mu},{sd}): mean err / rms {e_m:.1e}, var err / E[y^2] {e_v:.1e}, rstd rel err {e_r:.1e}, "
+          f"worst E[y^2]/var {float((q64 / v64).max()):.1f}")
+    assert e_m <= 1e-6 and e_v <= 1e-5
+    if abs(mu) <= 3.0:
+        assert e_r <= 1e-4
+
+
 def test_bn_eval_scale_shift(ops):
     Cc = 16
     gen = torch.Generator().manual_seed(5)

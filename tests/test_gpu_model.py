@@ -530,28 +530,20 @@ def test_staged_backward_completes_each_bucket_slice_when_its_stage_returns(sed,
     assert torch.equal(m.flat_grads()[valid], want[valid])
 
 
-def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
-    """learnable synthetic task (labels = a threshold on a band of the input), 40 Adam steps on 4 batches with the fused
-    trainer vs the CPU oracle's fit_step (beyond the 6 steps of golden g3).
-    * per-step losses within 3e-3 (measured 6e-4 .. 2.4e-3 depending on harmless changes of summation order: the run is
-      chaotic under Adam; the real gates are the float64-yardstick test and the single-step gradient test below);
-    * inference on the TRAINED weights is exact: the oracle's final state loaded into the HIP model gives its frame-wise
-      probabilities within 1e-5 and identical ER / F1 at 1 s;
-    * the HIP model's own trained weights: Adam turns rounding noise into +-lr steps on every coordinate whose gradient
-      is near zero (the conv biases in front of BatchNorm are the extreme case), so two fp32 implementations drift apart
-      at ~lr per step (measured: weights 2e-3, conv bias 2e-2 after 40 steps of lr 2e-3; torch itself moves by 8e-5 in
-      6 steps when only its thread count changes).  Their predictions must still be the same function: mean |dp| < 2e-2,
-      max < 0.2, same decision on every frame the oracle decides by more than 0.2.  (Measured 3e-3 .. 1e-2 / 0.03 .. 0.1
-      across harmless changes of summation order; torch-float32 itself ends 6e-3 / 0.05 from a float64 run of the same
-      loop.  The bounds that discriminate a defect from this chaos are in the float64-yardstick and single-step tests.)"""
+@pytest.fixture(scope="module")
+def forty_steps(sed):
+    """The 40-step Adam run of a learnable synthetic task (labels = a threshold on a band of the input; 4 batches of 16
+    sequences, lr 2e-3) done three times from the same state: the HIP fused trainer, the fp32 oracle's fit_step, and the
+    oracle in FLOAT64 (the yardstick).  Shared by the two trajectory tests below."""
     from oracle import crnn_ref
     from sed_crnn_amd.trainer import FusedTrainStep
-    LOSS_ATOL = 3e-3        # two fp32 runs of this loop: torch-f32 itself ends 1e-3 from the float64 run (see the float64-yardstick test below)
     torch.manual_seed(99)
     kw = dict(conv_channels=16, dropout=0.0, gru_hidden=16)
-    ref = crnn_ref.SedNetRef(**kw)
+    ref32 = crnn_ref.SedNetRef(**kw)
+    ref64 = crnn_ref.SedNetRef(**kw).double()
+    ref64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in ref32.state_dict().items()})
     m = sed.TimePooledCRNN(**kw)
-    m.load_state_dict(ref.state_dict())
+    m.load_state_dict(ref32.state_dict())
     m.cuda()
     g = torch.Generator().manual_seed(5)
     batches = []
@@ -560,36 +552,59 @@ def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed):
         band = x[:, 0, 8:16, :].mean(1)                                    # [B,T]
         y = (band.reshape(16, 8, 8).amax(2) > 0.45).float().unsqueeze(-1)  # [B,T',1]: learnable, ~55 % positive
         batches.append((x, y))
-    opt = torch.optim.Adam(ref.parameters(), lr=2e-3)
+    o32 = torch.optim.Adam(ref32.parameters(), lr=2e-3)
+    o64 = torch.optim.Adam(ref64.parameters(), lr=2e-3)
     step = FusedTrainStep(m, lr=2e-3, loss="bce")
-    lr_, lh_ = [], []
+    l32, l64, lh = [], [], []
     for it in range(40):
         x, y = batches[it % 4]
-        lr_.append(float(crnn_ref.fit_step(ref, opt, x, y)[0]))
-        lh_.append(step.step(x.cuda(), y.cuda())[0])
-    lh_ = torch.stack([l.reshape(()) for l in lh_]).cpu().numpy()
-    print(f"40-step trajectory: max |loss_hip - loss_torch| = {np.abs(lh_ - np.asarray(lr_)).max():.2e}")
-    np.testing.assert_allclose(lh_, np.asarray(lr_), atol=LOSS_ATOL)
-    assert lr_[-1] < 0.8 * lr_[0]                                          # it actually learns
-    ref.eval()
+        l32.append(float(crnn_ref.fit_step(ref32, o32, x, y)[0]))
+        l64.append(float(crnn_ref.fit_step(ref64, o64, x.double(), y.double())[0]))
+        lh.append(step.step(x.cuda(), y.cuda())[0])
+    lh = torch.stack([l.reshape(()) for l in lh]).cpu().numpy().astype(np.float64)
     xs = torch.cat([b[0] for b in batches])
     ys = torch.cat([b[1] for b in batches]).numpy()
+    for net in (ref32, ref64, m):
+        net.eval()
     with torch.no_grad():
-        pr = torch.sigmoid(ref(xs)).numpy()
-    m2 = sed.TimePooledCRNN(**kw)
-    m2.load_state_dict(ref.state_dict())
+        p32 = torch.sigmoid(ref32(xs)).double().numpy()
+        p64 = torch.sigmoid(ref64(xs.double())).numpy()
+        ph = torch.sigmoid(m(xs.cuda())).cpu().double().numpy()
+    return dict(kw=kw, ref32=ref32, m=m, xs=xs, ys=ys, l32=np.asarray(l32), l64=np.asarray(l64), lh=lh, p32=p32, p64=p64, ph=ph)
+
+
+def test_forty_step_trajectory_tracks_the_oracle_and_scores_agree(sed, forty_steps):
+    """40 Adam steps with the fused trainer vs the CPU oracle's fit_step (beyond the 6 steps of golden g3).
+    * inference on the TRAINED weights is exact: the oracle's final state loaded into the HIP model gives its frame-wise
+      probabilities within 1e-5 and identical ER / F1 at 1 s;
+    * the two fp32 trajectories themselves: Adam turns rounding noise into +-lr steps on every coordinate whose gradient is
+      near zero (the conv biases in front of BatchNorm are the extreme case), so two fp32 implementations of this loop
+      drift apart at ~lr per step and NO fixed bound on their distance means anything (round 2 had literal bounds here
+      and widened them when a harmless change of summation order tripped them).  The bound is therefore DERIVED from the
+      float64 run: the yardstick test below asserts d(HIP, f64) <= 3 d(torch32, f64) + floor, hence by the triangle
+      inequality d(HIP, torch32) <= 4 d(torch32, f64) + floor — asserted here with exactly those constants, nothing tuned."""
+    f = forty_steps
+    assert f["l32"][-1] < 0.8 * f["l32"][0]                                # it actually learns
+    assert f["lh"][-1] < 0.8 * f["lh"][0]
+    m2 = sed.TimePooledCRNN(**f["kw"])
+    m2.load_state_dict(f["ref32"].state_dict())
     m2.cuda().eval()
-    m.eval()
     with torch.no_grad():
-        p2 = torch.sigmoid(m2(xs.cuda())).cpu().numpy()
-        ph = torch.sigmoid(m(xs.cuda())).cpu().numpy()
-    np.testing.assert_allclose(p2, pr, atol=1e-5)
-    assert sed.metrics.compute_scores(p2 > 0.5, ys, 5) == sed.metrics.compute_scores(pr > 0.5, ys, 5)
-    d = np.abs(ph - pr)
-    print(f"40-step trajectory: HIP-trained vs torch-trained probabilities mean |dp| {d.mean():.2e}, max {d.max():.2e}")
-    assert d.mean() < 2e-2 and d.max() < 0.2, (d.mean(), d.max())
-    sure = np.abs(pr - 0.5) > 0.2
-    assert np.array_equal((ph > 0.5)[sure], (pr > 0.5)[sure])
+        p2 = torch.sigmoid(m2(f["xs"].cuda())).cpu().numpy()
+    np.testing.assert_allclose(p2, f["p32"], atol=1e-5)
+    assert sed.metrics.compute_scores(p2 > 0.5, f["ys"], 5) == sed.metrics.compute_scores(f["p32"] > 0.5, f["ys"], 5)
+    e_loss_t = np.abs(f["l32"] - f["l64"]).max()
+    e_p_t = np.abs(f["p32"] - f["p64"])
+    d_loss = np.abs(f["lh"] - f["l32"]).max()
+    d_p = np.abs(f["ph"] - f["p32"])
+    print(f"40-step trajectory, HIP vs torch-f32: loss {d_loss:.2e} (allowed {4 * e_loss_t + 1e-4:.2e}), probabilities mean "
+          f"{d_p.mean():.2e} (allowed {4 * e_p_t.mean() + 1e-4:.2e}), max {d_p.max():.2e} (allowed {4 * e_p_t.max() + 1e-3:.2e})")
+    assert d_loss <= 4.0 * e_loss_t + 1e-4
+    assert d_p.mean() <= 4.0 * e_p_t.mean() + 1e-4
+    assert d_p.max() <= 4.0 * e_p_t.max() + 1e-3
+    # decisions: wherever the float64 run decides by more than the allowed distance, HIP decides the same
+    sure = np.abs(f["p64"] - 0.5) > 3.0 * e_p_t.max() + 1e-3
+    assert np.array_equal((f["ph"] > 0.5)[sure], (f["p64"] > 0.5)[sure])
 
 
 def test_long_recording_single_sequence_inference_matches_oracle(sed):
@@ -649,52 +664,17 @@ def test_full_size_multichannel_configs_finite_separable_deterministic(sed, name
     torch.cuda.empty_cache()
 
 
-def test_forty_step_trajectory_is_as_close_to_float64_as_torch_float32_is(sed):
-    """Separates "two fp32 trajectories drift apart" from a real defect (round-1 verdict).  The 40-step run of
-    test_forty_step_trajectory_tracks_the_oracle_and_scores_agree is repeated a third time in FLOAT64 (the oracle net cast
-    to double): that run is the yardstick.  Freezing the zero-gradient conv biases alone does not stop the drift (measured:
-    weights still 2e-3 apart, max |dp| 3e-2), so the drift is Adam's amplification of rounding noise on EVERY coordinate
-    with a small gradient, and the question becomes whether the HIP path is any further from the float64 truth than torch's
-    own float32 path is.  Asserted: per-step losses and final probabilities of the HIP run are within 3x torch-float32's
-    own distance from float64 (plus a small floor), i.e. the HIP path is an fp32 implementation of the same computation,
-    not a different one."""
-    from oracle import crnn_ref
-    from sed_crnn_amd.trainer import FusedTrainStep
-    torch.manual_seed(99)
-    kw = dict(conv_channels=16, dropout=0.0, gru_hidden=16)
-    ref32 = crnn_ref.SedNetRef(**kw)
-    ref64 = crnn_ref.SedNetRef(**kw).double()
-    ref64.load_state_dict({k: v.double() if v.dtype.is_floating_point else v for k, v in ref32.state_dict().items()})
-    m = sed.TimePooledCRNN(**kw)
-    m.load_state_dict(ref32.state_dict())
-    m.cuda()
-    g = torch.Generator().manual_seed(5)
-    batches = []
-    for _ in range(4):
-        x = torch.randn(16, 1, 40, 64, generator=g)
-        band = x[:, 0, 8:16, :].mean(1)
-        y = (band.reshape(16, 8, 8).amax(2) > 0.45).float().unsqueeze(-1)
-        batches.append((x, y))
-    o32 = torch.optim.Adam(ref32.parameters(), lr=2e-3)
-    o64 = torch.optim.Adam(ref64.parameters(), lr=2e-3)
-    step = FusedTrainStep(m, lr=2e-3, loss="bce")
-    l32, l64, lh = [], [], []
-    for it in range(40):
-        x, y = batches[it % 4]
-        l32.append(float(crnn_ref.fit_step(ref32, o32, x, y)[0]))
-        l64.append(float(crnn_ref.fit_step(ref64, o64, x.double(), y.double())[0]))
-        lh.append(step.step(x.cuda(), y.cuda())[0])
-    lh = torch.stack([l.reshape(()) for l in lh]).cpu().numpy().astype(np.float64)
-    l32, l64 = np.asarray(l32), np.asarray(l64)
-    xs = torch.cat([b[0] for b in batches])
-    for net in (ref32, ref64, m):
-        net.eval()
-    with torch.no_grad():
-        p32 = torch.sigmoid(ref32(xs)).double().numpy()
-        p64 = torch.sigmoid(ref64(xs.double())).numpy()
-        ph = torch.sigmoid(m(xs.cuda())).cpu().double().numpy()
-    e_loss_t, e_loss_h = np.abs(l32 - l64).max(), np.abs(lh - l64).max()
-    e_p_t, e_p_h = np.abs(p32 - p64), np.abs(ph - p64)
+def test_forty_step_trajectory_is_as_close_to_float64_as_torch_float32_is(sed, forty_steps):
+    """Separates "two fp32 trajectories drift apart" from a real defect (round-1 verdict).  The FLOAT64 run of the same 40
+    steps (the oracle net cast to double) is the yardstick.  Freezing the zero-gradient conv biases alone does not stop the
+    drift (measured: weights still 2e-3 apart, max |dp| 3e-2), so the drift is Adam's amplification of rounding noise on
+    EVERY coordinate with a small gradient, and the question becomes whether the HIP path is any further from the float64
+    truth than torch's own float32 path is.  Asserted: per-step losses and final probabilities of the HIP run are within 3x
+    torch-float32's own distance from float64 (plus a small floor), i.e. the HIP path is an fp32 implementation of the
+    same computation, not a different one."""
+    f = forty_steps
+    e_loss_t, e_loss_h = np.abs(f["l32"] - f["l64"]).max(), np.abs(f["lh"] - f["l64"]).max()
+    e_p_t, e_p_h = np.abs(f["p32"] - f["p64"]), np.abs(f["ph"] - f["p64"])
     print(f"distance from the float64 run after 40 Adam steps: loss torch-f32 {e_loss_t:.2e} / HIP {e_loss_h:.2e}; "
           f"probabilities max torch-f32 {e_p_t.max():.2e} / HIP {e_p_h.max():.2e}, mean {e_p_t.mean():.2e} / {e_p_h.mean():.2e}")
     assert e_loss_h <= 3.0 * e_loss_t + 1e-4
