@@ -16,7 +16,13 @@ SOURCES = ["api.cpp", "conv.hip", "conv1.hip", "bnpool.hip", "gemm.hip", "gru.hi
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras.  logmel: the SLP vectoriser packs the FFT's scalar adds into v_pk_add_f32 and pays for it with ~600
 # v_mov per frame pair to build the register pairs (packed f32 is no faster than scalar on gfx950)
-EXTRA_FLAGS = {"logmel.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"logmel.hip": ["-fno-slp-vectorize"],
+               "conv.hip": ["-Rpass-analysis=kernel-resource-usage"]}
+# Kernels whose inline-asm loads are consumed after HAND-COUNTED s_waitcnt vmcnt(N) immediates (conv.hip: the fp32 and the
+# bf16x3 conv forward).  The counts are only right while hipcc keeps the load destinations in registers between the asm load
+# and its use: a spill (scratch store/reload) would insert memory operations the counts do not know about and the MFMAs
+# could read stale fragments without any test necessarily noticing.  The build therefore FAILS if one of them spills.
+NO_SPILL_KERNELS = {"conv.hip": ("conv3x3_mfma_fwd2_k", "conv3x3_mfma_fwd_bf16x3_k")}
 
 
 def _hipcc():
@@ -31,6 +37,26 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def check_no_spill(remarks, kernels):
+    """parse -Rpass-analysis=kernel-resource-usage output; returns the offending lines (empty = fine).  Every guarded kernel
+    must appear at least once, so a rename cannot silently disable the guard."""
+    import re
+    bad, seen, cur = [], set(), None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = next((k for k in kernels if k in m.group(1)), None)
+            if cur:
+                seen.add(cur)
+            continue
+        if cur:
+            m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", line)
+            if m and int(m.group(2)) != 0 and not m.group(1).startswith("SGPRs"):
+                bad.append(f"{cur}: {m.group(1)} = {m.group(2)}")
+    bad += [f"{k}: no resource-usage remark found (kernel renamed? update NO_SPILL_KERNELS)" for k in kernels if k not in seen]
+    return bad
 
 
 def build(force=False, verbose=False):
@@ -53,6 +79,14 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        src = next((a for a in cmd if a.endswith((".hip", ".cpp"))), "")
+        guarded = NO_SPILL_KERNELS.get(os.path.basename(src))
+        if guarded:
+            bad = check_no_spill(r.stderr, guarded)
+            if bad:
+                os.remove(cmd[cmd.index("-o") + 1])
+                raise RuntimeError("hand-counted-waitcnt kernels must not spill:\n" + "\n".join(bad))
+            return ""                                          # the resource remarks are not warnings
         return r.stderr
 
     with ThreadPoolExecutor(max_workers=4) as ex:

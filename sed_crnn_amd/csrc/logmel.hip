@@ -502,7 +502,16 @@ extern "C" int sed_logmel(const float* pcm, long n_samples, const void* tables, 
     SED_REQUIRE(pad_mode == 0 || pad_mode == 1, "logmel: pad_mode must be 0 (constant) or 1 (reflect)");
     const int words = (int)(tables_bytes / 4);
     SED_REQUIRE(tables_bytes % 16 == 0 && words >= LM_OFF_ENT + 64 + n_mels, "logmel: table blob of %zu bytes is malformed", tables_bytes);
+    SED_REQUIRE((size_t)words * 4 + (size_t)2 * 2 * LM_FRAME_SCR * sizeof(float) <= (size_t)160 * 1024,
+                "logmel: a table blob of %zu bytes leaves no room for the FFT scratch in the 160 KiB LDS", tables_bytes);
     const long frames = 1 + n_samples / hop;
     hipStream_t s = as_stream(stream);
-    return launch_logmel<LM_WPB>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
+    // 12 waves per workgroup when the tables leave room for their scratch (the two-band plan of a Slaney bank: 38 KB); a large
+    // list plan (up to 8 192 non-zeros = 67 KB of entries) runs with fewer waves per CU rather than being refused
+    const size_t per_wave = (size_t)2 * LM_FRAME_SCR * sizeof(float), room = (size_t)160 * 1024;
+    const size_t tb = (size_t)words * 4;
+    if (tb + 12 * per_wave <= room) return launch_logmel<12>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
+    if (tb + 8 * per_wave <= room) return launch_logmel<8>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
+    if (tb + 4 * per_wave <= room) return launch_logmel<4>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
+    return launch_logmel<2>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
 }

@@ -14,6 +14,7 @@ import torch
 from ._lib import check, lib, ptr, stream_ptr
 
 SR, NFFT, HOP, NB_MEL = 44_100, 2048, 1024, 40        # reference feature.py:29-32
+_LM_OFF_ENT = 8 + 2048 + 2048 + 1028                  # logmel.hip: header, window, inter-pass twiddles, pairing twiddles
 
 
 def slaney_mel_basis(sr=SR, n_fft=NFFT, n_mels=NB_MEL):
@@ -53,7 +54,7 @@ def build_tables(window, melfb, device):
     nbytes = lib().sed_logmel_tables_bytes(hp(fb), n_fft, n_mels)
     if nbytes == 0:
         raise ValueError(f"sed_logmel cannot plan this filterbank (n_fft must be {NFFT}, n_mels <= 128, and at most 8192 "
-                         f"non-zero weights so that the plan fits LDS); got n_fft={n_fft}, n_mels={n_mels}, "
+                         f"non-zero weights so that the plan fits LDS beside the FFT scratch; large plans run with fewer waves per CU); got n_fft={n_fft}, n_mels={n_mels}, "
                          f"{int(np.count_nonzero(fb))} non-zeros")
     blob = np.zeros(nbytes // 4, dtype=np.uint32)
     check(lib().sed_logmel_build_tables(hp(window), hp(fb), n_fft, n_mels, hp(blob), nbytes), "sed_logmel_build_tables")
@@ -77,7 +78,14 @@ def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=
     if tables is None:
         tables = _tables(y.device.index or 0, sr, n_fft, n_mels)
     else:
-        n_mels = int(tables[1])
+        # the library cannot read device memory to validate a caller's blob, and the kernel trusts its header: check it here
+        hdr = [int(v) & 0xFFFFFFFF for v in tables[:8].cpu().tolist()] if tables.numel() >= 8 else []
+        ok = (len(hdr) == 8 and hdr[0] == 0x4C4D3332 and hdr[4] == tables.numel() and 1 <= hdr[1] <= 128 and
+              ((hdr[5] == 0 and _LM_OFF_ENT + hdr[2] * 64 + hdr[1] <= hdr[4]) or
+               (hdr[5] == 1 and hdr[2] == 33 and _LM_OFF_ENT + 33 * 32 * 4 + hdr[1] * 4 <= hdr[4])))
+        if not ok:
+            raise ValueError("tables is not a blob written by feature.build_tables / sed_logmel_build_tables (bad header)")
+        n_mels = hdr[1]
     frames = 1 + y.numel() // hop
     out = torch.empty(frames, n_mels, device=y.device)
     inv = None

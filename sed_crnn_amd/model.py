@@ -144,6 +144,8 @@ class _NetFn(torch.autograd.Function):
         for p, g, al in zip(params, views, aliased):
             if al:
                 out.append(None)
+            elif not p.requires_grad:                      # frozen: the plan wrote its arena slice, nobody may see it
+                out.append(None)
             elif net._bound_grads and p.grad is None:
                 p.grad = g
                 out.append(None)
@@ -301,7 +303,7 @@ class HipCRNN(nn.Module):
         ``zero_grad(set_to_none=True)`` the next backward binds them again."""
         self._bound_grads = True
         for p, g in zip(self._arena_params, self._grad_views):
-            p.grad = g
+            p.grad = g if p.requires_grad else None        # a frozen parameter keeps grad None, like under torch autograd
 
     def zero_grad(self, set_to_none=True):
         self._arena_dirty = False

@@ -18,7 +18,11 @@ class FusedAdam(torch.optim.Optimizer):
     backward writes them in place and re-binds them after ``zero_grad(set_to_none=True)``), and the update is ONE launch
     over the arena.  There is one moment store: the per-parameter path (used for a step in which some gradient is not
     the arena view, e.g. frozen parameters or hand-set grads) works on views of the same m / v arenas, so switching paths
-    between steps never splits the Adam state.  ``max_grad_norm`` fuses clip_grad_norm_ into the step."""
+    between steps never splits the Adam state.  ``max_grad_norm`` fuses clip_grad_norm_ into the step.
+    Frozen parameters (``requires_grad_(False)``) keep ``grad is None`` and are skipped exactly like torch.optim.Adam skips
+    them (no update, no weight decay); the step then takes the per-parameter path.  One difference from torch remains: the
+    bias-correction step count is kept per parameter GROUP, so a parameter whose gradient is None only in SOME steps sees
+    the group's count rather than its own."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=None):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm)

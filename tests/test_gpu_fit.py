@@ -358,3 +358,35 @@ def test_config5_shaped_fold_trains_through_the_device_loader(sed):
         p = torch.sigmoid(net(x))
     sc = sed.metrics.compute_scores_device(p, y, 5)
     assert set(sc) == {"f1_overall_1sec", "er_overall_1sec"}
+
+
+def test_fused_adam_leaves_frozen_parameters_alone(sed):
+    """round-2 advisor: FusedAdam(model.parameters()) attaches to the arena; a parameter with requires_grad False must keep
+    grad None and must not move (torch.optim.Adam skips it: no update, no weight decay), while every other parameter gets
+    exactly the update of the un-frozen run (the arena gradients do not depend on who is frozen)."""
+    from oracle import crnn_ref
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=3)
+    x, y = x.cuda(), y.cuda()
+
+    def run(freeze):
+        torch.manual_seed(31)
+        m = sed.TimePooledCRNN(conv_channels=16, dropout=0.0, gru_hidden=16).cuda()
+        if freeze:
+            m.convs[0].weight.requires_grad_(False)
+            m.bns[1].bias.requires_grad_(False)
+        opt = sed.FusedAdam(m.parameters(), lr=1e-2, weight_decay=1e-2)
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        for _ in range(2):
+            opt.zero_grad()
+            sed.BCEWithLogitsLoss()(m(x), y).backward()
+            if freeze:
+                assert m.convs[0].weight.grad is None and m.bns[1].bias.grad is None
+            opt.step()
+        return before, {k: v.clone() for k, v in m.state_dict().items()}
+    b0, a0 = run(False)
+    b1, a1 = run(True)
+    assert torch.equal(a1["convs.0.weight"], b1["convs.0.weight"]) and torch.equal(a1["bns.1.bias"], b1["bns.1.bias"])
+    assert not torch.equal(a0["convs.0.weight"], b0["convs.0.weight"])
+    # step 1 is identical for every trainable parameter; in step 2 the frozen conv1 changes the forward, so only check movement
+    for k in ("gru.weight_ih_l0", "fc.weight", "convs.2.weight"):
+        assert not torch.equal(a1[k], b1[k])

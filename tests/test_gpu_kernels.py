@@ -437,6 +437,35 @@ def test_logmel_edges_odd_hop_custom_bank_and_shift_invariance(ops):
     assert torch.equal(a[3:1990], b[2:1989])
 
 
+@pytest.mark.parametrize("width,n_mels", [(60, 40), (120, 40), (100, 80), (64, 128)])
+def test_logmel_large_list_plans_run_with_fewer_waves_per_workgroup(ops, width, n_mels):
+    """round-2 advisor: sed_logmel_build_tables accepts list plans up to 8 192 non-zeros, but the 12-wave launch only has room
+    for ~3 200 beside its FFT scratch; larger plans now run with 8 / 4 / 2 waves per workgroup instead of being refused at
+    launch.  Dense-ish banks of 2 400 .. 8 192 non-zeros (overlapping rectangles) against the numpy power spectrum; a
+    caller-made blob with a damaged header is refused by feature.mbe."""
+    from oracle import logmel_ref
+    from sed_crnn_amd import feature
+    rng = np.random.RandomState(width + n_mels)
+    fb = np.zeros((n_mels, 1025), np.float32)
+    step = (1025 - width) // n_mels
+    for m in range(n_mels):
+        fb[m, step * m: step * m + width] = rng.rand(width).astype(np.float32) + 0.1
+    nnz = int(np.count_nonzero(fb))
+    tb = feature.build_tables(logmel_ref.hann_periodic(2048), fb, "cuda")
+    assert int(tb[5]) == 0 and 2000 < nnz <= 8192
+    y = rng.randn(37 * 1024 + 5).astype(np.float32)
+    ref = np.log(logmel_ref.stft_power(y) @ fb.T)
+    out = feature.mbe(torch.from_numpy(y).cuda(), tables=tb).cpu().numpy()
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4, err_msg=f"{nnz} non-zeros")
+    bad = tb.clone()
+    bad[2] = 4096                                           # iters beyond the blob
+    with pytest.raises(ValueError, match="bad header"):
+        feature.mbe(torch.from_numpy(y).cuda(), tables=bad)
+    with pytest.raises(ValueError, match="bad header"):
+        feature.mbe(torch.from_numpy(y).cuda(), tables=tb[:-4].contiguous())
+
+
 @pytest.mark.parametrize("B,Cin,Fm,T,Cout", [(2, 128, 40, 16, 128), (1, 32, 8, 8, 64), (3, 64, 40, 6, 32), (2, 128, 128, 8, 128)])
 def test_conv3x3_bf16x3_experiment_forward_and_dgrad(ops, B, Cin, Fm, T, Cout):
     """the opt-in 3-term bf16-split MFMA path (mode 1): forward, statistics partials and the data gradient (same kernel,
