@@ -48,6 +48,7 @@ struct SedProfScope {
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

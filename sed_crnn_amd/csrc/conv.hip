@@ -14,6 +14,7 @@
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define CV_CIC 32   // input channels per LDS chunk
@@ -873,7 +874,8 @@ struct WgradPlan {
     int kind;        // 0 small, 1 mfma
     int TT, FT, nft; // block tile: TT time rows x FT mel columns, nft mel tiles (mfma); FT == F on the small path
     int ntiles, ngroups, tblocks;
-    size_t lds, slab_floats;
+    int v2;          // mfma, exact fp32: the position-contiguous kernel (2 time rows x 40 or 32 mel columns)
+    size_t lds, slab_floats, zrow_floats;
 };
 
 // bytes of the two-buffer bf16 hi/lo LDS image of conv3x3_wgrad_bf16x3_k (x pitch 64 B, dy pitch 320 B, 16-position k-steps)
@@ -899,6 +901,16 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
                (p.TT + 4) * (p.FT + 2) * 8 <= 256 * WG_NX)
             p.TT += 2;
         p.lds = (size_t)2 * ((size_t)(p.TT + 2) * (p.FT + 2) * 32 + (size_t)p.TT * p.FT * 128) * sizeof(float);
+        // position-contiguous kernel: mel extents that cut into 40- or 32-column tiles (the BASELINE shapes: F = 40, F = 128)
+        if (mode == 0 && T >= 2 && !getenv("SED_WGRAD_V1")) {
+            const int n40 = cdiv(F, 40), n32 = cdiv(F, 32);
+            const int ft = (F % 8 == 0 && n40 * 40 == F) ? 40 : ((F % 8 == 0 && n32 * 32 == F) ? 32 : 0);
+            if (ft) {
+                p.v2 = 1; p.FT = ft; p.nft = F / ft; p.TT = 2;
+                const int px = ft + 4;
+                p.lds = (size_t)2 * ((size_t)32 * (4 * px + 4) + (size_t)128 * (2 * ft + 4)) * sizeof(float);
+            }
+        }
         if (mode == 1) {           // the padded dy pitch makes the image larger than the fp32 one: fewer time rows per tile
             p.TT = 1;
             while (p.TT + 1 <= 62 && p.TT + 1 <= T && wgrad_bf16x3_lds(p.TT + 1, p.FT) <= 160 * 1024) p.TT += 1;
@@ -917,6 +929,8 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     const int maxg = (p.kind == 1) ? 64 : 1024;
     p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
     p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
+    // the position-contiguous kernel reads rows outside the image from a zero-filled row behind the slabs
+    p.zrow_floats = p.v2 ? (size_t)(p.FT + 4) * (Cin > Cout ? Cin : Cout) + 64 : 0;
     return p;
 }
 
@@ -924,7 +938,7 @@ extern "C" size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T
     if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0) return 0;
     WgradPlan a = wgrad_plan(B, Cin, F, T, Cout, 0), b = wgrad_plan(B, Cin, F, T, Cout, 1);
     size_t m = a.slab_floats > b.slab_floats ? a.slab_floats : b.slab_floats;
-    return m * sizeof(float);
+    return (m + a.zrow_floats) * sizeof(float);
 }
 
 // small: slabs [group][ci][9][Cout]
@@ -1200,6 +1214,193 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
         }
 }
 
+// ── weight gradient, position-contiguous LDS image (round 3) ──
+// Same product, same grid / slabs / fixed-order reduction as conv3x3_mfma_wgrad_k, different operand path.  With ONE wave per
+// SIMD every instruction issued between two MFMAs costs MFMA issue time (round-2 ablation: ten ds_read_b32 per nine MFMAs
+// cost 12 %, the per-tile LDS-DMA 8.6 %), so the lever is instructions per MFMA.  K runs over positions, and the k index of an
+// MFMA can be assigned to positions freely as long as A and B agree: here a k-chunk is 8 consecutive mel positions of one
+// time row, MFMA j (0..3) takes position f0 + j in its k = 0 half (lanes 0-31) and f0 + 4 + j in its k = 1 half.  With the tile
+// held TRANSPOSED in LDS (x^T [32 ci][4 halo rows][PX], dy^T [128 co][2 rows][FT], positions contiguous) a lane fetches
+//   * its dy operands of all four MFMAs of a chunk with ONE ds_read_b128,
+//   * its x operands with TWO ds_read_b128 per time row of the halo: the three mel taps kh = 0..2 of MFMA j are elements
+//     j + kh of that 8-float window (register operands, no shuffles, no further reads),
+// i.e. 7 LDS reads per 36 MFMAs (9 taps x 4 k-steps) instead of 40, all offsets immediates of the fully unrolled tile body
+// (no address arithmetic in the loop).  The transposition happens while staging: global float4 (4 channels of one position) ->
+// registers -> four ds_write_b32; the next tile's 13-16 float4 per thread are loaded in batches two k-chunks ahead of their
+// commit, so at most two batches (32-40 VGPRs) are in flight and no load is waited for.  Row strides are an odd number of
+// 16-byte granules (conflict-free b128 reads across the 32 channel lanes).
+template <int FT>
+__global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, const float* __restrict__ zrow,
+    int B, int Cin, int F, int T, int Cout, int nft, int tblocks, int ntiles) {
+    constexpr int TT = 2, F2 = FT + 2;
+    constexpr int PX = FT + 4;                      // halo row pitch: the second b128 of the k = 1 half reaches column FT + 3
+    constexpr int XCI = (TT + 2) * PX + 4;          // floats per input channel
+    constexpr int DCO = TT * FT + 4;                // floats per output channel
+    static_assert(FT % 8 == 0 && PX % 4 == 0 && ((XCI / 4) & 1) == 1 && ((DCO / 4) & 1) == 1, "pitches: 16-B aligned, odd granule strides");
+    constexpr int XBUF = 32 * XCI, BUF = XBUF + 128 * DCO;
+    constexpr int HR = (TT + 2) * F2, MROWS = TT * FT;
+    constexpr int NCH = TT * (FT / 8);              // k-chunks (8 positions) per tile
+    // staging batches of the NEXT tile: batch b is loaded before the MFMAs of chunk b and committed before those of chunk
+    // NCH - NB + b, i.e. NCH - NB chunks (>= 5 us of MFMA work) later: a commit that has to wait for its load stalls the MFMA
+    // pipe (the wave issues in order), so the distance must cover the HBM latency under load with a wide margin
+    constexpr int NB = NCH >= 10 ? 4 : 3;
+    static_assert(NB >= 1 && 2 * NB <= NCH, "staging schedule");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
+    (void)HR; (void)MROWS;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
+
+    // Staging of the NEXT tile, organised so that the per-tile work is scalar: wave w stages halo row tt = w of x (GX slots of
+    // 8 positions x 8 channel quads) and half of time row tl = w >> 1 of dy (ND slots of 8 positions x 8 channel quads).  A
+    // slot's global address is a wave-uniform row pointer (clamped in scalar code) + a per-lane offset computed once; its
+    // LDS destination is a per-lane constant; whether the row lies inside the image is wave-uniform (zeros are written
+    // instead); only the two slots that hold the mel padding columns need a per-lane select, and only at a mel edge.
+    // 8 positions x 8 quads per wave store: bank = 16 (q mod 4) + position -> two-way conflicts at worst.
+    constexpr int GX = (F2 + 7) / 8;                // x slots per wave (one halo row)
+    constexpr int ND = (FT / 8) * 4 / 2;            // dy slots per wave (half a row: FT/8 position groups x 4 quad groups / 2 waves)
+    constexpr int NS = GX + ND;
+    const int lp = lane >> 3, lq = lane & 7;
+    int xso[GX], xld[GX], dso[ND], dld[ND];
+#pragma unroll
+    for (int k = 0; k < GX; ++k) {
+        int pc = k * 8 + lp;
+        pc = pc < F2 ? pc : F2 - 1;                 // slots past the row repeat its last position (same value written twice)
+        xso[k] = (pc - 1) * Cin + ci0 + 4 * lq;
+        xld[k] = (4 * lq) * XCI + wave * PX + pc;
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        const int j = (wave & 1) * ND + k, pg = j >> 2, qg = j & 3;
+        const int pp = pg * 8 + lp, q = qg * 8 + lq;
+        dso[k] = pp * Cout + co0 + 4 * q;
+        dld[k] = XBUF + (4 * q) * DCO + (wave >> 1) * FT + pp;
+    }
+    f32x4 st[NS];
+    // wave-uniform row pointers of the tile being staged.  A row outside the image (the halo row above the first / below the
+    // last time row of a sequence, the second row of a ragged last tile) is read from `zrow`, a zero-filled row in the
+    // caller's workspace: no per-element select, no second code path.
+    const float* xrow = x;
+    const float* drow = dy;
+    bool pad_l = false, pad_r = false;              // wave-uniform: the tile touches the left / right end of the mel axis
+    auto origin = [&](int tile) {
+        const int b = tile / (tblocks * nft), rem = tile - b * (tblocks * nft);
+        const int tb = rem / nft;
+        const int f0 = (rem - tb * nft) * FT, t0 = tb * TT;
+        const int tx = t0 + wave - 1, td = t0 + (wave >> 1);
+        pad_l = f0 == 0;
+        pad_r = f0 + FT >= F;
+        xrow = (unsigned)tx < (unsigned)T ? x + (((size_t)b * T + tx) * F + f0) * Cin : zrow + Cin - ci0;
+        drow = td < T ? dy + (((size_t)b * T + td) * F + f0) * Cout : zrow - co0;
+    };
+    auto load_item = [&](int k) {
+        if (k < GX) {
+            int off = xso[k];
+            // the padding columns (f = -1 at the left mel edge, f = F at the right one) are loaded from their valid neighbour
+            if (k == 0) off = (pad_l && lp == 0) ? off + Cin : off;
+            if (k * 8 + 7 >= F2 - 1) off = (pad_r && k * 8 + lp >= F2 - 1) ? (F2 - 3) * Cin + ci0 + 4 * lq : off;
+            st[k] = *(const f32x4*)(xrow + off);
+        } else {
+            st[k] = *(const f32x4*)(drow + dso[k - GX]);
+        }
+    };
+    auto commit_item = [&](int k, float* buf) {
+        float* d = buf + (k < GX ? xld[k] : dld[k - GX]);
+        constexpr f32x4 Z = {0, 0, 0, 0};
+        f32x4 v = st[k];
+        if (k < GX) {
+            if (k == 0 && pad_l && lp == 0) v = Z;                                       // the two padding columns of the mel axis
+            if (k * 8 + 7 >= F2 - 1 && pad_r && k * 8 + lp >= F2 - 1) v = Z;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e * (k < GX ? XCI : DCO)] = v[e];
+    };
+
+    // operand fetch of one k-chunk (time row tl, mel columns fc*8 .. fc*8+7)
+    // (the window's last two floats are never used: a b64 for the second half keeps hipcc from overlapping the dead registers of
+    // one b128 with the destination of the next, which made it serialise the reads with lgkmcnt waits)
+    struct Ops { f32x4 xa[3]; f32x2 xb[3]; f32x4 b; };
+    auto fetch_ops = [&](const float* buf, int tl, int fc, Ops& o) {
+        const float* xp = buf + r * XCI + tl * PX + fc * 8 + 4 * h;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            o.xa[kw] = *(const f32x4*)(xp + kw * PX);
+            o.xb[kw] = *(const f32x2*)(xp + kw * PX + 4);
+        }
+        o.b = *(const f32x4*)(buf + XBUF + (wave * 32 + r) * DCO + tl * FT + fc * 8 + 4 * h);
+    };
+    auto mfma_chunk = [&](const Ops& o) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int e = j + kh;
+                    const float a = e < 4 ? o.xa[kw][e] : o.xb[kw][e - 4];
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, o.b[j], acc[kh * 3 + kw], 0, 0, 0);
+                }
+    };
+
+    constexpr int BS = (NS + NB - 1) / NB;
+    int tile = blockIdx.x, cur = 0;
+    if (tile < ntiles) {                            // first tile: staged in one go
+        origin(tile);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) load_item(k);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) commit_item(k, smem);
+    }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int nxt = tile + gridDim.x;
+        origin(nxt < ntiles ? nxt : tile);          // the last tile re-stages itself (nobody reads that image): no branch
+        const float* buf = smem + cur * BUF;
+        float* nbuf = smem + (cur ^ 1) * BUF;       // last read before the previous barrier
+        // one tile: NCH chunks of 36 MFMAs; the staging of the next tile rides along (loads before chunks 0..NB-1, commits
+        // before chunks NCH-NB..NCH-1)
+        Ops o0, o1;
+        fetch_ops(buf, 0, 0, o0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            Ops& oc = (c & 1) ? o1 : o0;
+            Ops& on = (c & 1) ? o0 : o1;
+            // everything between the two scheduling barriers is issued BEFORE this chunk's 36 MFMAs (which depend on none of
+            // it): the next chunk's operands are a whole chunk ahead of their use
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < NCH) fetch_ops(buf, (c + 1) / (FT / 8), (c + 1) % (FT / 8), on);
+            if (c < NB) {
+#pragma unroll
+                for (int k = c * BS; k < (c + 1) * BS && k < NS; ++k) load_item(k);
+            }
+            if (c >= NCH - NB) {
+#pragma unroll
+                for (int k = (c - (NCH - NB)) * BS; k < (c - (NCH - NB) + 1) * BS && k < NS; ++k) commit_item(k, nbuf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_chunk(oc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+            sl[((size_t)k * Cin + ci0 + row) * Cout + co0 + wave * 32 + r] = acc[k][j];
+        }
+}
+
 // ── weight gradient on the 3-term bf16 split (EXPERIMENT, mode 1 of sed_conv3x3_wgrad_ex) ──
 // dW[tap][ci][co] = sum_pos x[pos+tap][ci] dy[pos][co]: the contraction index is the POSITION, while both operands are
 // stored position-major (channels contiguous), so the k-contiguous fragments of v_mfma_f32_32x32x16_bf16 are gathered with
@@ -1405,6 +1606,20 @@ extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* 
             conv3x3_wgrad_bf16x3_k<true><<<grid, 512, lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
         }
         SED_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
+        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+    } else if (p.kind == 1 && p.v2) {
+        dim3 grid(p.ngroups, Cin / 32, Cout / 128);
+        float* zrow = slabs + p.slab_floats;
+        hipError_t e = hipMemsetAsync(zrow, 0, p.zrow_floats * sizeof(float), s);
+        if (e != hipSuccess) { sed_set_error("conv3x3_wgrad: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        if (p.FT == 40) {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<40>, p.lds));
+            conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles);
+        } else {
+            SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<32>, p.lds));
+            conv3x3_mfma_wgrad2_k<32><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles);
+        }
+        SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     } else if (p.kind == 1) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
