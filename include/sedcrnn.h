@@ -87,6 +87,22 @@ int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw_
 int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                          void* workspace, int B, int Cin, int F, int T, int Cout, int mode, void* stream);
 
+/* Data gradient of conv block l (the convolution of dy with wp_dgrad) FUSED with the reduction pass of the BatchNorm / ReLU /
+ * max-pool / dropout backward of block l-1 (sed_bn_relu_pool_drop_bwd_reduce below), for the exact-fp32 MFMA shapes:
+ * dy [B][T][F][C] -> dx [B][T][F][Cin] = gradient of block l-1's pooled output, and partials [rows][2][Cin] = per-workgroup
+ * (sum g, sum g*xhat) of block l-1 — the input of sed_bn_bwd_finalize — formed in the epilogue from block l-1's own forward
+ * OUTPUT `pooled` [B][T][F][Cin] (channels-last): it is > 0 exactly where the gradient passes (element kept by the dropout AND
+ * ReLU gate open), g = dx / (1-p) there, and the normalised activation at the arg-max is (pooled (1-p) - beta) / gamma.
+ * conv_out_below [B][Ty][Fy][Cin], mean, rstd are only read for channels whose gamma is exactly 0 (pool_f, pool_t: block l-1's
+ * pool, Ty / pool_t == T, Fy / pool_f == F); conv_out_below may be NULL for a block that stores none (the recomputed first
+ * block: sed_conv1_bwd_apply_wgrad then supplies dgamma of those channels).  rows = sed_conv3x3_dgrad_bnred_rows(); 0 = shape not supported (use
+ * sed_conv3x3_fwd_ex + sed_bn_relu_pool_drop_bwd_reduce).  Replaces a 1.5x re-read of block l-1's conv output. */
+int sed_conv3x3_dgrad_bnred_rows(int B, int C, int F, int T, int Cin);
+int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                            const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                            const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                            int B, int C, int F, int T, int Cin, void* stream);
+
 /* ───────────── BatchNorm2d + ReLU + MaxPool2d + Dropout (sed.py:89-92,107; crnn_lightning.py:48-52) ─────────────
  * Training statistics: reduce the conv partials in a fixed order (double accumulation),
  * write mean/rstd and the fused scale/shift (scale = gamma*rstd, shift = beta - mean*scale),
@@ -162,12 +178,16 @@ int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, con
                          float* partials, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
                          float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 size_t sed_conv1_bwd_apply_workspace_bytes(int B, int Cin, int T, int C);
-/* dy is formed on the fly: writes dw_oihw [C][Cin][3][3] and the conv-bias gradient only. */
+/* dy is formed on the fly: writes dw_oihw [C][Cin][3][3] and the conv-bias gradient only.
+ * gamma / beta / dgamma (all three or none; may be NULL): when given, dgamma[c] is overwritten by this pass's own sum g*xhat
+ * for every channel with gamma[c] == 0 and beta[c] > 0 — the one case in which the reduction fused into the data gradient
+ * above (sed_conv3x3_dgrad_bnred) cannot form it, because this block stores no conv output. */
 int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias, const float* dout,
                               const float* scale, const float* shift, const float* mean, const float* rstd,
                               const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                               void* workspace, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
-                              float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
+                              float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                              const float* gamma, const float* beta, float* dgamma, void* stream);
 
 /* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
  * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.

@@ -340,10 +340,30 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_c_k(
 // Weights are streamed L2 -> registers in fragment order (one coalesced 1 KiB load per wave and k-group, no LDS, no
 // per-tap barrier); the halo tile is double-buffered in LDS with the next 32-channel chunk's global loads issued before
 // the MFMA loop of the current one: one barrier per chunk.
-template <int NCT, int MINW>
+// BNR (the kernel run as a DATA GRADIENT, y = the gradient of the pooled output of the block below): the epilogue also
+// forms that block's BatchNorm-backward sums, so its separate reduction pass (a re-read of its conv output) disappears.
+// They follow from the block's own pooled OUTPUT q (forward, same shape as y) without the conv output, the arg-max or
+// the dropout hash:   q = relu(max z) * keep_mask / (1-p)  is > 0 exactly where the gradient passes (kept AND gate open),
+//   g = y / (1-p) there (0 elsewhere),   and the BatchNorm output at the arg-max is z = q (1-p), so xhat = (z - beta) / gamma.
+// `stat` then receives (sum g, sum g*xhat) per block in the layout of the forward statistics (= sed_bn_bwd_finalize's
+// input).  A channel with gamma == 0 (z constant; measure zero) cannot recover xhat from z: if beta > 0 its xhat is read from
+// the conv output at the window's first element (arg-max of a tie), if beta <= 0 nothing passes and both sums are 0.
+struct ConvBnRed {
+    const float* pooled;     // [B][T][F][Cout] forward output of the block whose BatchNorm is being differentiated
+    const float* gamma;      // [Cout]
+    const float* beta;       // [Cout]
+    const float* ybelow;     // its conv output [B][Ty][Fy][Cout] and batch statistics: read for channels with gamma == 0 only
+    const float* mean;
+    const float* rstd;
+    float keep, inv_keep;    // 1 - p, 1 / (1 - p)
+    int pf, pt, Fy, Ty;      // pool and the extents of ybelow
+};
+
+template <int NCT, int MINW, bool BNR = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft) {
+    float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft,
+    ConvBnRed br = ConvBnRed{}) {
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -499,26 +519,53 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const int rq = lane >> 3, c4 = (lane & 7) * 4;
     // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
     const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
+    // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3)
+    f32x4 q_beta = {0, 0, 0, 0}, q_rg = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    unsigned slowmask = 0;                           // bit e: gamma == 0 and beta > 0 (xhat from the conv output)
+    if (BNR) {
+        const int cb = co0 + ct * 32 + c4;
+        q_beta = *(const f32x4*)(br.beta + cb);
+        const f32x4 gm = *(const f32x4*)(br.gamma + cb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q_rg[e] = gm[e] != 0.f ? 1.0f / gm[e] : 0.f;
+            if (gm[e] == 0.f && q_beta[e] > 0.f) slowmask |= 1u << e;
+        }
+    }
     auto store_tiles = [&](auto checked) {
         constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
         for (int i = 0; i < CV_MTW; ++i) {
             int mt = mp + i * MPARTS;
             if (mt < nMT) {
+                // BNR: this tile's pooled values, requested before the transpose so that they arrive under it
+                f32x4 pq[4];
+                if (BNR) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int p = mt * 32 + rq + 8 * k;
+                        const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                        const bool ok = !CHK || (p < MROWS && t0 + tl < T && f < F);
+                        pq[k] = (f32x4){0, 0, 0, 0};
+                        if (ok) pq[k] = *(const f32x4*)(br.pooled + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     int row = (j & 3) + 8 * (j >> 2) + 4 * h;
                     float v = acc[i][j] + bv;
                     tsc[row * 32 + r] = v;
-                    bool ok = true;
-                    if (CHK) {
-                        int p = mt * 32 + row;
-                        int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                        ok = p < MROWS && t0 + tl < T && f < F;
-                    }
-                    if (ok) {
-                        s1 += v;
-                        s2 += v * v;
+                    if (!BNR) {
+                        bool ok = true;
+                        if (CHK) {
+                            int p = mt * 32 + row;
+                            int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                            ok = p < MROWS && t0 + tl < T && f < F;
+                        }
+                        if (ok) {
+                            s1 += v;
+                            s2 += v * v;
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // one wave: LDS ops complete in order; compiler order only
@@ -529,8 +576,26 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                     int p = mt * 32 + row;
                     int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
                     f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
-                    if (!CHK || (p < MROWS && t0 + tl < T && f < F))
-                        *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                    const bool ok = !CHK || (p < MROWS && t0 + tl < T && f < F);
+                    if (ok) *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                    if (BNR && ok) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pv = pq[k][e];
+                            const float g = pv > 0.f ? v[e] * br.inv_keep : 0.f;
+                            float xh = (pv * br.keep - q_beta[e]) * q_rg[e];
+                            if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
+                                const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
+                                xh = 0.f;                 // (no stored conv output: the block's own apply pass supplies this dgamma)
+                                if (br.ybelow) {
+                                    const float yv = br.ybelow[(((size_t)b * br.Ty + (size_t)(t0 + tl) * br.pt) * br.Fy + (size_t)f * br.pf) * Cout + cc];
+                                    xh = (yv - br.mean[cc]) * br.rstd[cc];
+                                }
+                            }
+                            a1[e] += g;
+                            a2[e] += g * xh;
+                        }
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -540,10 +605,23 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     if (interior) store_tiles(std::false_type{});
     else store_tiles(std::true_type{});
     if (stat) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
         float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
-        if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        if (BNR) {
+            // lanes with equal c4 (8 row groups) hold partial sums of the same four channels
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { a1[e] += __shfl_xor(a1[e], o, 64); a2[e] += __shfl_xor(a2[e], o, 64); }
+            }
+            if (lane < 8) {
+                *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
+                *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
+            }
+        } else {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
+        }
         __syncthreads();
         const size_t row = (size_t)b * gridDim.x + blockIdx.x;
         if (tid < 2 * WROWS) {
@@ -866,6 +944,39 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
         }
     }
     SED_LAUNCH_CHECK("conv3x3_fwd");
+    return 0;
+}
+
+// Data gradient of conv block l fused with the BatchNorm-backward reduction of block l-1 (see ConvBnRed above): the exact-fp32
+// MFMA kernel with the BNR epilogue.  dy [B][T][F][C] -> dx [B][T][F][Cin] (= the gradient of block l-1's pooled output) and
+// partials [rows][2][Cin] = (sum g, sum g*xhat) of block l-1, rows = sed_conv3x3_dgrad_bnred_rows (0: this shape does not take
+// the MFMA path, use sed_conv3x3_fwd_ex + sed_bn_relu_pool_drop_bwd_reduce).
+extern "C" int sed_conv3x3_dgrad_bnred_rows(int B, int C, int F, int T, int Cin) {
+    ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
+    return (p.kind == 1 && p.nct == 4) ? p.rows : 0;
+}
+
+extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                                       const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                                       const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                                       int B, int C, int F, int T, int Cin, void* stream) {
+    SED_REQUIRE(dy && wp_dgrad && dx && partials && pooled && gamma && beta && mean && rstd, "conv3x3_dgrad_bnred: null pointer");
+    SED_REQUIRE(B > 0 && C > 0 && F > 0 && T > 0 && Cin > 0, "conv3x3_dgrad_bnred: bad shape B=%d C=%d F=%d T=%d Cin=%d", B, C, F, T, Cin);
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f && pool_f >= 1 && pool_t >= 1, "conv3x3_dgrad_bnred: bad drop_p / pool");
+    SED_REQUIRE(Ty / pool_t == T && Fy / pool_f == F, "conv3x3_dgrad_bnred: conv output %dx%d does not pool (%d,%d) to %dx%d", Ty, Fy, pool_t, pool_f, T, F);
+    ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
+    SED_REQUIRE(p.kind == 1 && p.nct == 4, "conv3x3_dgrad_bnred: C=%d -> Cin=%d does not take the 128-wide MFMA path", C, Cin);
+    if ((size_t)B * T * F * C >= ((size_t)1 << 32)) {
+        sed_set_error("conv3x3_dgrad_bnred: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernels", (size_t)B * T * F * C);
+        return -1;
+    }
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_FWD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
+    ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty};
+    dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
+    SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
+    conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft, br);
+    SED_LAUNCH_CHECK("conv3x3_dgrad_bnred");
     return 0;
 }
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
         if (MODE >= 2) { mu = *(const f32x4*)(mean + cg * 4); rs = *(const f32x4*)(rstd + cg * 4); }
         if (MODE == 3) { sg = *(const f32x4*)(sum_g + cg * 4) * invN; sgx = *(const f32x4*)(sum_gx + cg * 4) * invN; }
     }
-    f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};              // stats / (sum g, sum g xhat) / dbias
+    f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};              // stats / (sum g, sum g xhat) / (dbias, sum g xhat again)
     f32x4 dw[MODE == 3 ? 9 * CIN : 1];
     if (MODE == 3) {
 #pragma unroll
@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                                     float xh = (v[k] - mu[k]) * rs[k];
                                     float gk = (bidx[k] == widx) ? g[k] : 0.f;
                                     o[k] = sc[k] * (gk - sg[k] - xh * sgx[k]);
+                                    a2[k] += gk * xh;          // dgamma once more (used for channels with gamma == 0, see the reduce kernel)
                                 }
                                 a1 += o;
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
     if (MODE == 1) return;
     // block reduction in fixed slot order, NVC values per round: the apply pass runs beside the conv weight-gradient kernel,
     // which leaves ~38 KB of LDS per CU, so its 1 + 9*CIN values go through a 20 KB buffer in rounds of 5
-    constexpr int NV = (MODE == 3) ? 1 + 9 * CIN : 2;
+    constexpr int NV = (MODE == 3) ? 2 + 9 * CIN : 2;       // MODE 3: dbias, 9*CIN weight-gradient taps, sum g*xhat
     constexpr int NVC = (MODE == 3) ? 5 : 2;
     float* red = smem;                                        // [nslots][NVC][C]
 #pragma unroll
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
             for (int j = 0; j < NVC; ++j) {
                 const int v = v0 + j;
                 if (v < NV) {
-                    f32x4 val = (v == 0) ? a1 : (MODE == 3 ? dw[(v - 1) < 9 * CIN ? (v - 1) : 0] : a2);
+                    f32x4 val = (v == 0) ? a1 : ((MODE == 3 && v <= 9 * CIN) ? dw[(v - 1) < 9 * CIN ? (v - 1) : 0] : a2);
                     *(f32x4*)(red + (slot * NVC + j) * C + cg * 4) = val;
                 }
             }
@@ -248,13 +249,18 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
     }
 }
 
-// dW[co][ci][tap] = sum_r part[r][1 + tap*Cin + ci][co]   (row 0 of each block is the bias gradient)
+// dW[co][ci][tap] = sum_r part[r][1 + tap*Cin + ci][co]   (row 0 of each block is the bias gradient, the last row sum g*xhat)
 // (256-thread workgroups: it runs on the auxiliary stream beside the conv weight gradients, see reduce_rows_k)
+// The last row repeats dgamma with the decisions of the apply pass.  It is only USED for a channel whose gamma is exactly 0
+// with beta > 0: there the fused reduction in the data gradient above (conv.hip, ConvBnRed) cannot recover xhat from the
+// block's output, and this block keeps no conv output to read it from.
 __global__ __launch_bounds__(256) void conv1_wgrad_reduce_k(const float* __restrict__ part, int rows, int Cin, int C,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ dgamma) {
     __shared__ double s1[32][9];
     const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
-    const int NV = 1 + 9 * Cin, n = NV * C;
+    const int NV = 2 + 9 * Cin, n = NV * C;
     const int i = blockIdx.x * 8 + cl;
     double a = 0.0;
     if (i < n)
@@ -267,7 +273,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_reduce_k(const float* __restr
         for (int s = 0; s < 32; ++s) A += s1[s][cl];
         int which = i / C, co = i - which * C;
         if (which == 0) db[co] = (float)A;
-        else {
+        else if (which == NV - 1) {
+            if (dgamma && gamma && beta && gamma[co] == 0.f && beta[co] > 0.f) dgamma[co] = (float)A;
+        } else {
             int tc = which - 1, tap = tc / Cin, ci = tc - tap * Cin;
             dw[((size_t)co * Cin + ci) * 9 + tap] = (float)A;
         }
@@ -497,14 +505,15 @@ extern "C" int sed_conv1_bwd_reduce(const float* x, const float* wp, const float
 }
 
 extern "C" size_t sed_conv1_bwd_apply_workspace_bytes(int B, int Cin, int T, int C) {
-    return (size_t)sed_conv1_fused_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
+    return (size_t)sed_conv1_fused_rows(B, T) * (2 + 9 * Cin) * C * sizeof(float);
 }
 
 extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias, const float* dout,
                                          const float* scale, const float* shift, const float* mean, const float* rstd,
                                          const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                                          void* workspace, int B, int Cin, int F, int T, int C, int pf, int pt,
-                                         float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream) {
+                                         float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                         const float* gamma, const float* beta, float* dgamma, void* stream) {
     SED_REQUIRE(x && wp && dout && scale && shift && mean && rstd && sum_g && sum_gx && dw_oihw && dbias && workspace,
                 "conv1_bwd_apply_wgrad: null pointer");
     C1_CHECK("conv1_bwd_apply_wgrad");
@@ -512,8 +521,8 @@ extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const 
     SedProfScope prof(SED_K_BN_BWD_APPLY, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
     c1_launch<3>(x, wp, bias, scale, shift, mean, rstd, sum_g, sum_gx, dout, nullptr, (float*)workspace, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_bwd_apply_wgrad");
-    int rows = sed_conv1_fused_rows(B, T), n = (1 + 9 * Cin) * C;
-    conv1_wgrad_reduce_k<<<cdiv(n, 8), 256, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias);
+    int rows = sed_conv1_fused_rows(B, T), n = (2 + 9 * Cin) * C;
+    conv1_wgrad_reduce_k<<<cdiv(n, 8), 256, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias, gamma, beta, dgamma);
     SED_LAUNCH_CHECK("conv1_wgrad_reduce");
     return 0;
 }

@@ -9,7 +9,8 @@
 
 namespace {
 
-struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop; };
+struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop;
+               int red_rows; };   // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
 struct GruL { int in, H; };
 
 struct Layout {
@@ -88,6 +89,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         if (q.bn_rows > max_bn_rows) max_bn_rows = q.bn_rows;
         if (q.C > maxC) maxC = q.C;
         Cin = q.C; T = q.Tp; F = q.Fp;
+    }
+    // exact-fp32 MFMA blocks: the data gradient of block l forms the BatchNorm-backward sums of block l-1 in its epilogue
+    for (int l = 1; l < c->n_conv; ++l) {
+        const ConvL& q = L->cv[l];
+        const int rr = (c->conv_mode == 0) ? sed_conv3x3_dgrad_bnred_rows(c->B, q.C, q.F, q.T, q.Cin) : 0;
+        L->cv[l - 1].red_rows = rr;
+        if (rr > max_bn_rows) max_bn_rows = rr;
     }
     L->c1_stat_ws = cv.take(c1_stat_ws);
     L->Tp = T; L->Fp = F; L->feat = Cin * F; L->M = c->B * T;
@@ -338,7 +346,9 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
     SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
     float* sum_g = ws + L.sum_g;
     float* sum_gx = sum_g + q.C;
-    if (part & 1) {
+    if ((part & 1) && q.red_rows > 0) {       // the partial sums already lie in bn_part (epilogue of the data gradient above)
+        SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.red_rows, q.C, sum_g, sum_gx, g->bn_g[l], g->bn_b[l], st));
+    } else if (part & 1) {
         if (q.fused)
             SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                          ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
@@ -354,7 +364,9 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
         if (q.fused) {
             SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                               ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
-                                              ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, seed_dev, st));
+                                              ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, seed_dev,
+                                              q.red_rows > 0 ? p->bn_g[l] : nullptr, q.red_rows > 0 ? p->bn_b[l] : nullptr,
+                                              q.red_rows > 0 ? g->bn_g[l] : nullptr, st));
         } else {
             SED_TRY(sed_bn_relu_pool_drop_bwd_apply(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                                     ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, ws + L.dconv[l],
@@ -363,6 +375,20 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
         }
     }
     return 0;
+}
+
+// data gradient of block l >= 1 into gradA; where the shapes allow it the epilogue also writes the BatchNorm-backward partial
+// sums of block l-1 into bn_part (cv[l-1].red_rows > 0), which bn_backward then only finalises
+static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, float* ws, int l, void* st) {
+    const ConvL& q = L.cv[l];
+    const ConvL& u = L.cv[l - 1];
+    if (u.red_rows > 0)
+        return sed_conv3x3_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
+                                       p->bn_g[l - 1], p->bn_b[l - 1],
+                                       u.fused ? nullptr : ws + L.conv_out[l - 1],      // a recomputed first block keeps no conv output: its
+                                       ws + L.mean[l - 1], ws + L.rstd[l - 1],          // gamma == 0 channels are finished by its apply pass
+                                       u.drop, u.pf, u.pt, u.F, u.T, c->B, q.C, q.F, q.T, q.Cin, st);
+    return sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, c->B, q.C, q.F, q.T, q.Cin, c->conv_mode, st);
 }
 
 extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, const sed_net_params* g,
@@ -526,8 +552,8 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             if (!q.fused && !wg0_with_bn) SED_TRY(wgrad(0));     // fused block 0: its BN pass already produced every gradient
             continue;
         }
-        // data gradient = the same convolution with flipped, transposed taps
-        SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
+        // data gradient = the same convolution with flipped, transposed taps (+ the BatchNorm-backward sums of the block below)
+        SED_TRY(dgrad(L, c, p, ws, l, stream));
         if (l > 1) {
             if (top_wgrad_on_aux && l == top) {
                 // it starts here, beside BN(l-1) and then the next data gradient (config 2: step -65 us; started any
@@ -588,8 +614,7 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         SED_TRY(sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
                                      B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
-        if (l > 0)
-            SED_TRY(sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, B, q.C, q.F, q.T, q.Cin, c->conv_mode, stream));
+        if (l > 0) SED_TRY(dgrad(L, c, p, ws, l, stream));
     }
     return 0;
 }

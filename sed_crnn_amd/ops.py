@@ -102,6 +102,23 @@ def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out
     return dy, dgamma, dbeta, dbias
 
 
+def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0):
+    """data gradient of a conv block + the BatchNorm-backward sums of the block below in its epilogue
+    -> (dx [B,T,F,Cin], sum_g [Cin], sum_gx [Cin]); dy [B,T,F,C], wd = the dgrad packing [9,Cin,C]"""
+    B, T, F, Cc = dy.shape
+    Cin = pooled.shape[-1]
+    rows = lib().sed_conv3x3_dgrad_bnred_rows(B, Cc, F, T, Cin)
+    assert rows > 0, "shape does not take the fused MFMA path"
+    dx = torch.empty(B, T, F, Cin, device=dy.device)
+    part = torch.empty(rows, 2, Cin, device=dy.device)
+    check(lib().sed_conv3x3_dgrad_bnred(ptr(_f32c(dy)), ptr(_f32c(wd)), ptr(dx), ptr(part), ptr(_f32c(pooled)), ptr(gamma), ptr(beta),
+                                        ptr(_f32c(y_below)), ptr(mean), ptr(rstd), drop_p, pool_f, pool_t, y_below.shape[2],
+                                        y_below.shape[1], B, Cc, F, T, Cin, stream_ptr()), "conv3x3_dgrad_bnred")
+    sum_g, sum_gx = torch.empty(Cin, device=dy.device), torch.empty(Cin, device=dy.device)
+    check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cin, ptr(sum_g), ptr(sum_gx), None, None, stream_ptr()), "bn_bwd_finalize")
+    return dx, sum_g, sum_gx
+
+
 def gemm(A, B, bias=None, out=None, beta=0.0):
     """out = A @ B (+bias) (+beta*out) for 2-D fp32 CUDA tensors with arbitrary (unit-along-one-axis) strides."""
     M, K = A.shape
@@ -257,5 +274,5 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
     dw, db = torch.empty_like(w), torch.empty(Cc, device=x.device)
     check(L.sed_conv1_bwd_apply_wgrad(ptr(x), ptr(wf), ptr(bias), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
                                       ptr(sum_g), ptr(sum_gx), ptr(dw), ptr(db), ptr(ws), B, Cin, F, T, Cc, pool_f, pool_t,
-                                      drop_p, seed, None, stream_ptr()), "conv1_bwd_apply_wgrad")
+                                      drop_p, seed, None, None, None, None, stream_ptr()), "conv1_bwd_apply_wgrad")
     return out, dw, db, dgamma, dbeta

@@ -176,6 +176,47 @@ def test_conv1_stats_from_input_moments_vs_float64_sums(ops, cin, mu, sd):
         assert e_r <= 1e-4
 
 
+@pytest.mark.parametrize("B,Ty,Fy,pf,pt,p", [(3, 16, 40, 1, 2, 0.5), (2, 12, 40, 1, 2, 0.0), (2, 9, 40, 1, 2, 0.5), (1, 8, 41, 2, 2, 0.3),
+                                              (2, 6, 128, 1, 2, 0.5), (1, 20, 8, 2, 1, 0.25)])
+def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B, Ty, Fy, pf, pt, p):
+    """sed_conv3x3_dgrad_bnred: the data gradient of a 128-channel block whose epilogue also forms (sum g, sum g*xhat) of the
+    block below from that block's pooled OUTPUT, against the separate passes (sed_conv3x3_fwd_ex on the dgrad weights +
+    sed_bn_relu_pool_drop_bwd_reduce, which re-reads the conv output, finds the arg-max and regenerates the dropout mask):
+    dx bit for bit (same main loop), the sums to rounding.  Ragged pooling tails, mel pooling, dropout on / off, edge tiles,
+    and channels with gamma == 0 (beta > 0: xhat from the conv output at the window's first element; beta <= 0: nothing
+    passes) are all in."""
+    C = 128
+    gen = torch.Generator().manual_seed(B * 100 + Ty + Fy)
+    yb = torch.randn(B, Ty, Fy, C, generator=gen).cuda()                        # conv output of the block below (channels-last)
+    gamma = (torch.rand(C, generator=gen) + 0.5)
+    beta = torch.randn(C, generator=gen) * 0.3
+    gamma[3], beta[3] = 0.0, 0.5
+    gamma[77], beta[77] = 0.0, -0.2
+    gamma[100] = -0.7                                                            # a negative scale flips the arg-max
+    gamma, beta = gamma.cuda(), beta.cuda()
+    n = B * Ty * Fy
+    flat = yb.reshape(-1, C)
+    part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).reshape(1, 2, C).contiguous()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    mean, rstd, scale, shift = ops.bn_finalize_train(part, n, gamma, beta, rm, rv)
+    seed = 99
+    pooled = ops.bn_relu_pool_drop_fwd(yb, scale, shift, pf, pt, drop_p=p, seed=seed)        # [B,T,F,C]
+    T, Fm = Ty // pt, Fy // pf
+    dy = (torch.randn(B, T, Fm, C, generator=gen) * 0.1).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=gen) / np.sqrt(9 * C)).cuda()
+    _, wd = ops.conv3x3_pack(w)
+    dx_ref, _ = ops.conv3x3_fwd(dy, wd, None, False, want_stats=False)
+    _, dgamma_ref, dbeta_ref, _ = ops.bn_relu_pool_drop_bwd(yb, dx_ref, scale, shift, mean, rstd, pf, pt, drop_p=p, seed=seed)
+    dx, sum_g, sum_gx = ops.conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p)
+    assert torch.equal(dx, dx_ref)
+    keep_scale = 1.0 / (1.0 - p)
+    mag = float((dx_ref.abs() * keep_scale).sum(dim=(0, 1, 2)).max())        # an upper bound of sum |g| per channel
+    close(sum_g, dbeta_ref, atol=2e-6 * mag, rtol=1e-4)
+    close(sum_gx, dgamma_ref, atol=6e-6 * mag, rtol=1e-4)
+    assert float(sum_g[77].abs()) == 0.0 and float(sum_gx[77].abs()) == 0.0      # gamma 0, beta < 0: the gate is shut everywhere
+    assert float(sum_gx[3].abs()) > 0.0
+
+
 def test_bn_eval_scale_shift(ops):
     Cc = 16
     gen = torch.Generator().manual_seed(5)
