@@ -1487,16 +1487,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
             // it): the next chunk's operands are a whole chunk ahead of their use
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < NCH) fetch_ops(buf, (c + 1) / (FT / 8), (c + 1) % (FT / 8), on);
-            if (c < NB) {
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
+            if (c < NB && !(WG_ABL & 1)) {
 #pragma unroll
                 for (int k = c * BS; k < (c + 1) * BS && k < NS; ++k) load_item(k);
             }
-            if (c >= NCH - NB) {
+            if (c >= NCH - NB && !(WG_ABL & 2)) {
 #pragma unroll
                 for (int k = (c - (NCH - NB)) * BS; k < (c - (NCH - NB) + 1) * BS && k < NS; ++k) commit_item(k, nbuf);
             }
-            __builtin_amdgcn_sched_barrier(0);
             mfma_chunk(oc);
+            // Issue order inside the chunk: ONE non-MFMA instruction per MFMA gap.  A global_load_dwordx4 holds the wave's
+            // issue for ~60 cycles and an LDS instruction for 8-16 (one wave per SIMD issues in order), each fits in the 64-cycle
+            // shadow of the MFMA in front of it, but a burst of them in front of the chunk does not (measured: the four loads
+            // of a batch issued back to back cost 4 % of the kernel, the commits 5 %).
+#pragma unroll
+            for (int g = 0; g < 34; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x322, 1, 0);      // one of: VALU, VMEM read, DS read, DS write
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
