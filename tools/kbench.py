@@ -75,6 +75,16 @@ def main():
         for name, fn, fl in cases:
             ms = timeit(fn, a.iters)
             print(f"gemm {name}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+    if a.what in ("gru", "all"):
+        for H, T in ((128, 32), (256, 64)):
+            gi = torch.randn(B, T, 2, 3 * H, device=dev) * 0.5
+            whh = [torch.randn(3 * H, H, device=dev) / H ** 0.5 for _ in range(2)]
+            bhh = [torch.randn(3 * H, device=dev) * 0.1 for _ in range(2)]
+            ms = timeit(lambda: ops.gru_seq_fwd(gi, whh, bhh), a.iters)
+            out, saved = ops.gru_seq_fwd(gi, whh, bhh)
+            dout = torch.randn_like(out)
+            ms2 = timeit(lambda: ops.gru_seq_bwd(dout, saved, whh, want_bias=True), a.iters)
+            print(f"gru_seq H{H} T{T}: fwd {ms:.3f} ms ({ms / T * 1e3:.2f} us/step)  bwd {ms2:.3f} ms ({ms2 / T * 1e3:.2f} us/step)")
     if a.what in ("bn", "all"):
         for T in (256, 128, 64):
             y = torch.randn(B, T, 40, 128, device=dev)
