@@ -14,7 +14,6 @@
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 #define CV_CIC 32   // input channels per LDS chunk
@@ -1013,7 +1012,7 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
             p.TT += 2;
         p.lds = (size_t)2 * ((size_t)(p.TT + 2) * (p.FT + 2) * 32 + (size_t)p.TT * p.FT * 128) * sizeof(float);
         // position-contiguous kernel: mel extents that cut into 40- or 32-column tiles (the BASELINE shapes: F = 40, F = 128)
-        if (mode == 0 && T >= 2 && !getenv("SED_WGRAD_V1")) {
+        if (mode == 0 && T >= 2) {
             const int n40 = cdiv(F, 40), n32 = cdiv(F, 32);
             const int ft = (F % 8 == 0 && n40 * 40 == F) ? 40 : ((F % 8 == 0 && n32 * 32 == F) ? 32 : 0);
             if (ft) {
@@ -1487,14 +1486,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
             // it): the next chunk's operands are a whole chunk ahead of their use
             __builtin_amdgcn_sched_barrier(0);
             if (c + 1 < NCH) fetch_ops(buf, (c + 1) / (FT / 8), (c + 1) % (FT / 8), on);
-#ifndef WG_ABL
-#define WG_ABL 0
-#endif
-            if (c < NB && !(WG_ABL & 1)) {
+            if (c < NB) {
 #pragma unroll
                 for (int k = c * BS; k < (c + 1) * BS && k < NS; ++k) load_item(k);
             }
-            if (c >= NCH - NB && !(WG_ABL & 2)) {
+            if (c >= NCH - NB) {
 #pragma unroll
                 for (int k = (c - (NCH - NB)) * BS; k < (c - (NCH - NB) + 1) * BS && k < NS; ++k) commit_item(k, nbuf);
             }

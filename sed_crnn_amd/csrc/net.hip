@@ -4,7 +4,6 @@
 // No host synchronisation, no allocation: every intermediate lives in the caller's workspace at
 // offsets that are a pure function of the config, so a step is capturable in a hipGraph and the
 // backward can be issued in stages (head+GRU, conv3, conv2, conv1) to overlap the RCCL all-reduce.
-#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -539,7 +538,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     const int top = L.n_conv - 1;
     // the top block's weight gradient runs on the auxiliary stream (decided by the configuration alone: the stages of one
     // backward may arrive in separate calls)
-    const bool top_wgrad_on_aux = s_aux && top > 1 && !getenv("SED_SCHED_TOPWG_MAIN");
+    const bool top_wgrad_on_aux = s_aux && top > 1;
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
