@@ -168,11 +168,17 @@ int sed_conv1_fused_rows(int B, int T);
  * second moments of the 9*Cin shifted inputs (one pass over x, fp64 quadratic form per channel).  Writes ONE partial
  * row [1][2][C]; workspace >= sed_conv1_stats_workspace_bytes(). */
 size_t sed_conv1_stats_workspace_bytes(int B, int Cin, int T);
+/* moments (may be NULL): device array of sed_conv1_moments_doubles(Cin) doubles that receives the input moments themselves
+ * ([9*Cin] first moments, then the upper triangle of the second moments row by row) for sed_conv1_bwd_wgrad. */
+size_t sed_conv1_moments_doubles(int Cin);
 int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials, void* workspace,
-                    int B, int Cin, int F, int T, int C, void* stream);
+                    int B, int Cin, int F, int T, int C, double* moments, void* stream);
+/* argmax_bits (may be NULL; (1,2) pool only): one byte per output channel quad, [B][T/2][F][C/4], bit k = the second time row of
+ * the window holds the maximum of channel 4q+k (the first maximum wins a tie): what sed_conv1_bwd_wgrad routes the gradient by. */
 int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
                                     const float* shift, float* out, int B, int Cin, int F, int T, int C,
-                                    int pool_f, int pool_t, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
+                                    int pool_f, int pool_t, float drop_p, uint64_t seed, const uint64_t* seed_dev,
+                                    unsigned char* argmax_bits, void* stream);
 int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
                          const float* scale, const float* shift, const float* mean, const float* rstd,
                          float* partials, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
@@ -188,6 +194,22 @@ int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const float* bias
                               void* workspace, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
                               float drop_p, uint64_t seed, const uint64_t* seed_dev,
                               const float* gamma, const float* beta, float* dgamma, void* stream);
+
+/* Backward of the recomputed first block WITHOUT recomputing it ((1,2) pool; replaces sed_conv1_bwd_apply_wgrad where
+ * sed_conv1_rgrad_supported() and the BatchNorm-backward sums are already known, e.g. from sed_conv3x3_dgrad_bnred):
+ *   dW_k = scale [ R_k - (sum_g/N) S1_k - (sum_gx/N) rstd ( b S1_k + sum_k' w_k' G_kk' - mean S1_k ) ],   N = B*T*F,
+ * with S1 / G the input moments of sed_conv1_stats and R_k = sum over pooled elements of g * x[arg-max position + tap k], the
+ * only sum this pass forms: g = dout / (1-p) where `pooled` (the block's forward output) is > 0, the arg-max row from
+ * `argmax_bits`.  No convolution, dropout hash or BatchNorm arithmetic is redone.  Also writes the conv-bias gradient and, given
+ * gamma / beta / dgamma, dgamma of channels with gamma == 0 and beta > 0 (see sed_conv1_bwd_apply_wgrad).
+ * workspace >= sed_conv1_bwd_wgrad_workspace_bytes(). */
+int sed_conv1_rgrad_supported(int Cin, int F, int T, int C, int pool_f, int pool_t);
+size_t sed_conv1_bwd_wgrad_workspace_bytes(int B, int Cin, int T, int C);
+int sed_conv1_bwd_wgrad(const float* x, const float* dout, const float* pooled, const unsigned char* argmax_bits,
+                        const double* moments, const float* wp, const float* bias, const float* mean, const float* rstd,
+                        const float* scale, const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
+                        void* workspace, int B, int Cin, int F, int T, int C, float drop_p,
+                        const float* gamma, const float* beta, float* dgamma, void* stream);
 
 /* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
  * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.

@@ -63,8 +63,12 @@ SIGNATURES = {
     "sed_conv1_fused_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sed_conv1_fused_rows": (_i, [_i, _i]),
     "sed_conv1_stats_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sed_conv1_stats": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
-    "sed_conv1_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
+    "sed_conv1_moments_doubles": (_sz, [_i]),
+    "sed_conv1_stats": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _stream]),
+    "sed_conv1_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _fp, _stream]),
+    "sed_conv1_rgrad_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sed_conv1_bwd_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sed_conv1_bwd_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _stream]),
     "sed_conv1_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_conv1_bwd_apply_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _fp, _fp, _fp, _stream]),

@@ -158,6 +158,13 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
 #pragma unroll
                             for (int k = 0; k < 4; ++k) m[k] = fmaxf(m[k], z[k]);
                         }
+                    if (P12 && partials) {           // arg-max of the (1,2) window, one bit per channel (first maximum wins a tie)
+                        const f32x4 z0 = vw[0] * sc + sh, z1 = vw[1] * sc + sh;
+                        unsigned bt = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) bt |= (z1[k] > z0[k] ? 1u : 0u) << k;
+                        reinterpret_cast<unsigned char*>(partials)[oi >> 2] = (unsigned char)bt;
+                    }
                     if (drop_p > 0.f) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) m[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
@@ -358,7 +365,8 @@ __global__ __launch_bounds__(256) void conv1_gram_k(const float* __restrict__ x,
 // stat[0][c] = sum y, stat[1][c] = sum y^2 of channel c (one partial row in the format of the stored path's conv epilogue)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __restrict__ partials, int nblk, const float* __restrict__ wp,
-                                                             const float* __restrict__ bias, double count, int C, float* __restrict__ stat) {
+                                                             const float* __restrict__ bias, double count, int C, float* __restrict__ stat,
+                                                             double* __restrict__ gram_out) {
     constexpr int NK = 9 * CIN, NG = NK + NK * (NK + 1) / 2;
     __shared__ double G[NG];
     __shared__ double Gq[4][64];
@@ -379,6 +387,8 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
         }
     }
     __syncthreads();
+    if (gram_out)
+        for (int i = threadIdx.x; i < NG; i += 256) gram_out[i] = G[i];
     for (int c = threadIdx.x; c < C; c += 256) {
         double w[NK];
 #pragma unroll
@@ -394,6 +404,142 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
         }
         stat[c] = (float)(count * b + ws1);
         stat[C + c] = (float)(q + 2.0 * b * ws1 + count * b * b);
+    }
+}
+
+// ── backward of the recomputed block WITHOUT recomputing it (round 3) ──
+// The old apply pass (MODE 3) recomputes both conv outputs of every window, the dropout hash and BatchNorm, forms dy for both
+// rows and accumulates 2 x 9*CIN taps: ~240 vector instructions per output quad, and beside the MFMA weight gradients (where it
+// has to run) vector work advances at 1/8 of its rate.  Everything except ONE sum per tap follows from quantities already at
+// hand.  With v_k(pos) the 9*CIN shifted inputs, dy = sc (g_r - sg - xhat sgx), xhat = (y - mu) rs and y = b + sum_k' w_k' v_k':
+//   dW_k = sum_pos v_k dy = sc [ R_k - sg S1_k - sgx rs ( b S1_k + sum_k' w_k' G_kk' - mu S1_k ) ]
+// S1 and G are the input moments of the forward statistics pass (conv1_gram_k, kept in fp64), sg / sgx come from the fused
+// reduction in the data gradient above, and R_k = sum over POOLED elements of g * v_k(arg-max position) is the only new sum:
+// g = dout / (1-p) where the block's pooled output is > 0 (kept and gate open), the arg-max row is one bit per element written
+// by the forward pass.  No conv, no hash, no BatchNorm arithmetic: 2 x 9*CIN FMAs per quad and two streamed tensors.
+// The conv-bias gradient sum_pos dy = sc [ sum g - N sg - sgx rs (sum y - N mu) ] and, for a channel with gamma == 0, dgamma
+// = rs ( b sum g + sum_k w_k R_k - mu sum g ) come out of the same sums in the assembling kernel.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_rgrad_k(
+    const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ pooled,
+    const unsigned char* __restrict__ bits, float* __restrict__ partials, int B, int F, int T, int C, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    float* halo = smem;                                       // [(TT+2)][F2][CIN]
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2, nslots = 256 / C4;
+    const int cg = tid % C4, slot = tid / C4;
+    const bool active = slot < nslots;
+    const int tblocks = (T + C1_TT - 1) / C1_TT, ntiles = B * tblocks;
+    const int Tp = T >> 1;
+    f32x4 a1 = {0, 0, 0, 0};
+    f32x4 rk[9 * CIN];
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k) rk[k] = (f32x4){0, 0, 0, 0};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tblocks, t0 = (tile - b * tblocks) * C1_TT;
+        __syncthreads();
+        c1_stage<CIN>(halo, x, b, t0, F, T);
+        __syncthreads();
+        if (!active) continue;
+        for (int op = slot; op < (C1_TT / 2) * F; op += nslots) {
+            const int tpl = op / F, f = op - tpl * F;
+            const int tp = (t0 >> 1) + tpl;
+            if (tp >= Tp) break;
+            const size_t oi = ((((size_t)b * Tp + tp) * F + f) * C4 + cg) * 4;
+            const f32x4 g = *(const f32x4*)(dout + oi), pv = *(const f32x4*)(pooled + oi);
+            const unsigned bt = bits[oi >> 2];
+            f32x4 g0, g1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gv = pv[k] > 0.f ? g[k] * inv_keep : 0.f;
+                const bool second = (bt >> k) & 1u;
+                g0[k] = second ? 0.f : gv;
+                g1[k] = second ? gv : 0.f;
+                a1[k] += gv;
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float hv[4][CIN];                              // the four halo rows under the window's two conv rows
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) hv[rr][ci] = halo[((tpl * 2 + rr) * F2 + f + kh) * CIN + ci];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) rk[(kh * 3 + kw) * CIN + ci] += hv[kw][ci] * g0 + hv[kw + 1][ci] * g1;
+            }
+        }
+    }
+    // block reduction in fixed slot order, 5 values per round through a 20 KB buffer (as conv1_fused_k)
+    constexpr int NV = 1 + 9 * CIN, NVC = 5;
+    float* red = smem;                                        // [nslots][NVC][C]
+#pragma unroll
+    for (int v0 = 0; v0 < NV; v0 += NVC) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NVC; ++j) {
+                const int v = v0 + j;
+                if (v < NV) *(f32x4*)(red + (slot * NVC + j) * C + cg * 4) = (v == 0) ? a1 : rk[(v - 1) < 9 * CIN ? (v - 1) : 0];
+            }
+        }
+        __syncthreads();
+        const int nv = (NV - v0 < NVC) ? NV - v0 : NVC;
+        for (int i = tid; i < nv * C; i += 256) {
+            int j = i / C, c = i - j * C;
+            float a = 0.f;
+            for (int s2 = 0; s2 < nslots; ++s2) a += red[(s2 * NVC + j) * C + c];
+            partials[(size_t)blockIdx.x * NV * C + (size_t)(v0 + j) * C + c] = a;
+        }
+    }
+}
+
+// index of G(k, k2), k <= k2, in the moment vector [S1 (NK) | upper triangle row by row] of conv1_gram_k
+__device__ __forceinline__ int c1_gidx(int k, int k2, int NK) { return NK + k * NK - (k * (k - 1)) / 2 + (k2 - k); }
+
+// one workgroup per output channel: R and sum g summed over the partial rows in fp64 (fixed order), then the closed form
+__global__ __launch_bounds__(64) void conv1_wgrad_assemble_k(
+    const float* __restrict__ part, int rows, int Cin, int C, const double* __restrict__ gram, const float* __restrict__ wp,
+    const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
+    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, double count, float* __restrict__ dw, float* __restrict__ db,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma) {
+    const int co = blockIdx.x, NK = 9 * Cin, NV = 1 + NK;
+    __shared__ double sv[37];                                 // [0] sum g, [1..NK] R_k
+    const int lane = threadIdx.x;
+    for (int v = 0; v < NV; ++v) {
+        double a = 0.0;
+        for (int r = lane; r < rows; r += 64) a += (double)part[((size_t)r * NV + v) * C + co];
+        a = wave_sum_d(a);
+        if (lane == 0) sv[v] = a;
+    }
+    __syncthreads();
+    const double b = bias ? (double)bias[co] : 0.0, mu = mean[co], rs = rstd[co], sc = scale[co];
+    const double sg = (double)sum_g[co] / count, sgx = (double)sum_gx[co] / count;
+    if (lane < NK) {
+        const int k = lane;
+        double wg = 0.0;                                       // sum_k' w_k' G(k, k')
+        for (int k2 = 0; k2 < NK; ++k2) {
+            const double w2 = (double)wp[((size_t)(k2 / Cin) * C + co) * Cin + (k2 % Cin)];
+            wg += w2 * gram[k <= k2 ? c1_gidx(k, k2, NK) : c1_gidx(k2, k, NK)];
+        }
+        const double s1 = gram[k];
+        const double val = sc * (sv[1 + k] - sg * s1 - sgx * rs * (b * s1 + wg - mu * s1));
+        const int tap = k / Cin, ci = k - tap * Cin;
+        dw[((size_t)co * Cin + ci) * 9 + tap] = (float)val;
+    }
+    if (lane == 63) {
+        double ws1 = 0.0, wr = 0.0;
+        for (int k2 = 0; k2 < NK; ++k2) {
+            const double w2 = (double)wp[((size_t)(k2 / Cin) * C + co) * Cin + (k2 % Cin)];
+            ws1 += w2 * gram[k2];
+            wr += w2 * sv[1 + k2];
+        }
+        const double sum_y = count * b + ws1;
+        db[co] = (float)(sc * (sv[0] - count * sg - sgx * rs * (sum_y - count * mu)));
+        if (dgamma && gamma && beta && gamma[co] == 0.f && beta[co] > 0.f)       // see sed_conv1_bwd_apply_wgrad
+            dgamma[co] = (float)(rs * (b * sv[0] + wr - mu * sv[0]));
     }
 }
 
@@ -447,7 +593,7 @@ extern "C" size_t sed_conv1_stats_workspace_bytes(int B, int Cin, int T) {
 }
 
 extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials, void* workspace,
-                               int B, int Cin, int F, int T, int C, void* stream) {
+                               int B, int Cin, int F, int T, int C, double* gram_out, void* stream) {
     SED_REQUIRE(x && wp && stat_partials && workspace, "conv1_stats: null pointer");
     const int pf = 1, pt = 1;
     C1_CHECK("conv1_stats");
@@ -467,11 +613,11 @@ extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bia
     if (Cin == 1) {
         conv1_gram_k<1><<<grid, 256, lds, s>>>(x, (float*)workspace, B, F, T);
         SED_LAUNCH_CHECK("conv1_gram");
-        conv1_gram_finalize_k<1><<<1, 256, 0, s>>>((const float*)workspace, grid, wp, bias, count, C, stat_partials);
+        conv1_gram_finalize_k<1><<<1, 256, 0, s>>>((const float*)workspace, grid, wp, bias, count, C, stat_partials, gram_out);
     } else {
         conv1_gram_k<2><<<grid, 256, lds, s>>>(x, (float*)workspace, B, F, T);
         SED_LAUNCH_CHECK("conv1_gram");
-        conv1_gram_finalize_k<2><<<1, 256, 0, s>>>((const float*)workspace, grid, wp, bias, count, C, stat_partials);
+        conv1_gram_finalize_k<2><<<1, 256, 0, s>>>((const float*)workspace, grid, wp, bias, count, C, stat_partials, gram_out);
     }
     SED_LAUNCH_CHECK("conv1_gram_finalize");
     return 0;
@@ -480,13 +626,14 @@ extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bia
 extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float* bias, const float* scale,
                                                const float* shift, float* out, int B, int Cin, int F, int T, int C,
                                                int pf, int pt, float drop_p, uint64_t seed, const uint64_t* seed_dev,
-                                               void* stream) {
+                                               unsigned char* argmax_bits, void* stream) {
     SED_REQUIRE(x && wp && scale && shift && out, "conv1_fwd: null pointer");
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_fwd: drop_p=%f out of [0,1)", drop_p);
     C1_CHECK("conv1_fwd");
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_FWD, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
-    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr, B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
+    SED_REQUIRE(!argmax_bits || (pf == 1 && pt == 2), "conv1_fwd: arg-max bits exist for the (1,2) pool only");
+    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, reinterpret_cast<float*>(argmax_bits), B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
     SED_LAUNCH_CHECK("conv1_fwd");
     return 0;
 }
@@ -524,5 +671,41 @@ extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const 
     int rows = sed_conv1_fused_rows(B, T), n = (2 + 9 * Cin) * C;
     conv1_wgrad_reduce_k<<<cdiv(n, 8), 256, 0, s>>>((const float*)workspace, rows, Cin, C, dw_oihw, dbias, gamma, beta, dgamma);
     SED_LAUNCH_CHECK("conv1_wgrad_reduce");
+    return 0;
+}
+
+// ── the backward of the recomputed block from its pooled output, arg-max bits and input moments (see conv1_rgrad_k) ──
+extern "C" int sed_conv1_rgrad_supported(int Cin, int F, int T, int C, int pf, int pt) {
+    return sed_conv1_fused_supported(Cin, F, T, C, pf, pt) && pf == 1 && pt == 2;
+}
+extern "C" size_t sed_conv1_moments_doubles(int Cin) { const int nk = 9 * Cin; return (size_t)nk + (size_t)nk * (nk + 1) / 2; }
+extern "C" size_t sed_conv1_bwd_wgrad_workspace_bytes(int B, int Cin, int T, int C) {
+    return (size_t)sed_conv1_fused_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
+}
+extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const float* pooled, const unsigned char* argmax_bits,
+                                   const double* moments, const float* wp, const float* bias, const float* mean, const float* rstd,
+                                   const float* scale, const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
+                                   void* workspace, int B, int Cin, int F, int T, int C, float drop_p,
+                                   const float* gamma, const float* beta, float* dgamma, void* stream) {
+    SED_REQUIRE(x && dout && pooled && argmax_bits && moments && wp && mean && rstd && scale && sum_g && sum_gx && dw_oihw && dbias && workspace,
+                "conv1_bwd_wgrad: null pointer");
+    SED_REQUIRE(sed_conv1_rgrad_supported(Cin, F, T, C, 1, 2), "conv1_bwd_wgrad: shape Cin=%d F=%d T=%d C=%d is not supported", Cin, F, T, C);
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_bwd_wgrad: drop_p=%f out of [0,1)", drop_p);
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_BN_BWD_APPLY, s, 2.0 * 4.0 * B * C * (double)(T / 2) * F);
+    const size_t lds = c1_lds(Cin, F, C, 3);
+    const int grid = sed_conv1_fused_rows(B, T);
+    const float inv_keep = 1.f / (1.f - drop_p);
+    if (Cin == 1) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv1_rgrad_k<1><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        conv1_rgrad_k<2><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
+    }
+    SED_LAUNCH_CHECK("conv1_rgrad");
+    conv1_wgrad_assemble_k<<<C, 64, 0, s>>>((const float*)workspace, grid, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
+                                           (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);
+    SED_LAUNCH_CHECK("conv1_wgrad_assemble");
     return 0;
 }

@@ -10,7 +10,8 @@
 namespace {
 
 struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop;
-               int red_rows; };   // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
+               int red_rows;      // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
+               int rgrad; };      // recomputed first block: its weight gradient comes from the pooled output, arg-max bits and input moments   // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
 struct GruL { int in, H; };
 
 struct Layout {
@@ -21,7 +22,7 @@ struct Layout {
     // float offsets into the workspace
     size_t wp_f[SED_MAX_CONV], wp_d[SED_MAX_CONV], conv_out[SED_MAX_CONV], stat[SED_MAX_CONV];
     size_t mean[SED_MAX_CONV], rstd[SED_MAX_CONV], scale[SED_MAX_CONV], shift[SED_MAX_CONV];
-    size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV], c1_stat_ws;
+    size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV], c1_stat_ws, c1_bits, c1_mom;
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
@@ -77,7 +78,14 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->bn_sums[l] = cv.take((size_t)2 * q.C);
         if (npool > max_pool) max_pool = npool;
         if (q.fused) {
+            // The moment-based backward (sed_conv1_bwd_wgrad: no recompute, 2.7x fewer vector instructions) is NOT used by the plan
+            // for now: measured at config 2 it runs 1.14 ms beside the MFMA weight gradient where the recomputing pass runs 1.44,
+            // but its two small companions (finalise 0.33, assemble 0.15 beside) put the tail at 0.28 ms against 0.11 — an HBM- or
+            // VALU-bound kernel beside a persistent MFMA kernel advances at ~1/8 of its rate whatever it does.  Kept as an entry.
+            q.rgrad = 0;
             c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
+            const size_t w2 = sed_conv1_bwd_wgrad_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
+            if (w2 > c1_ws) c1_ws = w2;
             const size_t sws = sed_conv1_stats_workspace_bytes(c->B, q.Cin, q.T) / sizeof(float);
             if (sws > c1_stat_ws) c1_stat_ws = sws;
         } else {
@@ -98,6 +106,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         if (rr > max_bn_rows) max_bn_rows = rr;
     }
     L->c1_stat_ws = cv.take(c1_stat_ws);
+    L->c1_bits = L->cv[0].rgrad ? cv.take(((size_t)c->B * L->cv[0].Tp * L->cv[0].Fp * (L->cv[0].C / 4) + 3) / 4) : 0;      // one byte per channel quad
+    L->c1_mom = L->cv[0].rgrad ? cv.take(2 * sed_conv1_moments_doubles(L->cv[0].Cin)) : 0;                               // doubles (the carver's 256-byte granules keep them aligned)
     L->Tp = T; L->Fp = F; L->feat = Cin * F; L->M = c->B * T;
     const size_t M = (size_t)L->M;
     int in = L->feat, maxH = 0, max2H = 0;
@@ -204,7 +214,8 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
             SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
                                                 q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
             if (q.fused) {
-                if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C, stream));
+                if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C,
+                                                      q.rgrad ? (double*)(ws + L.c1_mom) : nullptr, stream));
             } else {
                 SED_TRY(sed_conv3x3_fwd_ex(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
                                            training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
@@ -228,7 +239,8 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         if (q.fused)
             SED_TRY(sed_conv1_bn_relu_pool_drop_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.scale[l], ws + L.shift[l],
                                                     ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
-                                                    training ? q.drop : 0.f, layer_seed(seed, l), seed_dev, stream));
+                                                    training ? q.drop : 0.f, layer_seed(seed, l), seed_dev,
+                                                    (training && q.rgrad) ? (unsigned char*)(ws + L.c1_bits) : nullptr, stream));
         else
             SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
                                               q.T, q.F, q.C, q.pf, q.pt, last, training ? q.drop : 0.f,
@@ -361,7 +373,13 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
     }
     if (part & 2) {
         if (count_scale != 1.f) SED_TRY(sed_scale(sum_g, 2 * q.C, 1.f / count_scale, st));   // global sums / global count
-        if (q.fused) {
+        if (q.fused && q.rgrad) {
+            SED_TRY(sed_conv1_bwd_wgrad(x, ws + L.gradA, ws + L.pooled[l], (const unsigned char*)(ws + L.c1_bits), (const double*)(ws + L.c1_mom),
+                                        ws + L.wp_f[l], p->conv_b[l], ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, sum_gx,
+                                        g->conv_w[l], g->conv_b[l], ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.drop,
+                                        q.red_rows > 0 ? p->bn_g[l] : nullptr, q.red_rows > 0 ? p->bn_b[l] : nullptr,
+                                        q.red_rows > 0 ? g->bn_g[l] : nullptr, st));
+        } else if (q.fused) {
             SED_TRY(sed_conv1_bwd_apply_wgrad(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                               ws + L.mean[l], ws + L.rstd[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
                                               ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, q.drop, sd, seed_dev,

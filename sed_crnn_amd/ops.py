@@ -246,9 +246,11 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
                               ptr(grad_scale), ptr(step_state), stream_ptr()), "adam_step")
 
 
-def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p=0.0, seed=0, eps=1e-5):
+def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p=0.0, seed=0, eps=1e-5, moments_path=False):
     """First conv block through the recompute-fused entries (train statistics).
-    x [B,Cin,F,T] -> pooled [B,T/pt,F/pf,C]; with dout also (dw, dbias, dgamma, dbeta)."""
+    x [B,Cin,F,T] -> pooled [B,T/pt,F/pf,C]; with dout also (dw, dbias, dgamma, dbeta).
+    moments_path: the weight gradient from the pooled output, the arg-max bits and the input moments (sed_conv1_bwd_wgrad)
+    instead of the recomputing apply pass (sed_conv1_bwd_apply_wgrad)."""
     B, Cin, F, T = x.shape
     Cc = w.shape[0]
     L = lib()
@@ -257,12 +259,14 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
     rows = L.sed_conv1_fused_rows(B, T)
     stat = torch.empty(1, 2, Cc, device=x.device)
     sws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, Cin, T) // 4 + 1, device=x.device)
-    check(L.sed_conv1_stats(ptr(_f32c(x)), ptr(wf), ptr(bias), ptr(stat), ptr(sws), B, Cin, F, T, Cc, stream_ptr()), "conv1_stats")
+    mom = torch.empty(L.sed_conv1_moments_doubles(Cin), device=x.device, dtype=torch.float64) if moments_path else None
+    check(L.sed_conv1_stats(ptr(_f32c(x)), ptr(wf), ptr(bias), ptr(stat), ptr(sws), B, Cin, F, T, Cc, ptr(mom), stream_ptr()), "conv1_stats")
     rm, rv = torch.zeros(Cc, device=x.device), torch.ones(Cc, device=x.device)
     mean, rstd, scale, shift = bn_finalize_train(stat, B * T * F, gamma, beta, rm, rv, eps=eps)
     out = torch.empty(B, T // pool_t, F // pool_f, Cc, device=x.device)
+    bits = torch.empty(out.numel() // 4, device=x.device, dtype=torch.uint8) if moments_path else None
     check(L.sed_conv1_bn_relu_pool_drop_fwd(ptr(x), ptr(wf), ptr(bias), ptr(scale), ptr(shift), ptr(out), B, Cin, F, T, Cc,
-                                            pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_fwd")
+                                            pool_f, pool_t, drop_p, seed, None, ptr(bits), stream_ptr()), "conv1_fwd")
     if dout is None:
         return out
     part = torch.empty(rows, 2, Cc, device=x.device)
@@ -270,8 +274,15 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
                                  ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_bwd_reduce")
     sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=x.device) for _ in range(4))
     check(L.sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta), stream_ptr()), "bn_bwd_finalize")
-    ws = torch.empty(L.sed_conv1_bwd_apply_workspace_bytes(B, Cin, T, Cc) // 4 + 1, device=x.device)
     dw, db = torch.empty_like(w), torch.empty(Cc, device=x.device)
+    if moments_path:
+        assert L.sed_conv1_rgrad_supported(Cin, F, T, Cc, pool_f, pool_t)
+        ws = torch.empty(L.sed_conv1_bwd_wgrad_workspace_bytes(B, Cin, T, Cc) // 4 + 1, device=x.device)
+        check(L.sed_conv1_bwd_wgrad(ptr(x), ptr(dout), ptr(out), ptr(bits), ptr(mom), ptr(wf), ptr(bias), ptr(mean), ptr(rstd),
+                                    ptr(scale), ptr(sum_g), ptr(sum_gx), ptr(dw), ptr(db), ptr(ws), B, Cin, F, T, Cc, drop_p,
+                                    ptr(gamma), ptr(beta), ptr(dgamma), stream_ptr()), "conv1_bwd_wgrad")
+        return out, dw, db, dgamma, dbeta
+    ws = torch.empty(L.sed_conv1_bwd_apply_workspace_bytes(B, Cin, T, Cc) // 4 + 1, device=x.device)
     check(L.sed_conv1_bwd_apply_wgrad(ptr(x), ptr(wf), ptr(bias), ptr(dout), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
                                       ptr(sum_g), ptr(sum_gx), ptr(dw), ptr(db), ptr(ws), B, Cin, F, T, Cc, pool_f, pool_t,
                                       drop_p, seed, None, None, None, None, stream_ptr()), "conv1_bwd_apply_wgrad")

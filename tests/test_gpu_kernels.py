@@ -117,6 +117,54 @@ def test_bn_relu_pool_fwd_bwd(ops, B, T, Fm, Cc, pf, pt, tcf):
 @pytest.mark.parametrize("B,Cin,Fm,T,Cc,pf,pt", [(2, 1, 40, 16, 8, 1, 2), (3, 1, 40, 8, 128, 1, 2), (2, 2, 40, 8, 128, 1, 2),
                                                  (2, 2, 40, 8, 32, 5, 1), (2, 1, 8, 12, 16, 2, 2), (1, 1, 40, 4, 64, 1, 1)])
 def test_conv1_fused_block_vs_torch(ops, B, Cin, Fm, T, Cc, pf, pt):
+    _conv1_fused_case(ops, B, Cin, Fm, T, Cc, pf, pt, False)
+
+
+@pytest.mark.parametrize("B,Cin,Fm,T,Cc,drop,shift", [(2, 1, 40, 16, 8, 0.0, 0.0), (3, 1, 40, 8, 128, 0.5, 0.0), (2, 2, 40, 8, 128, 0.3, 0.0),
+                                                      (4, 1, 40, 64, 128, 0.5, 1.5), (2, 2, 24, 12, 32, 0.0, -2.0), (16, 1, 40, 256, 128, 0.5, 0.0)])
+def test_conv1_backward_from_pooled_output_bits_and_moments_vs_float64(ops, B, Cin, Fm, T, Cc, drop, shift):
+    """sed_conv1_bwd_wgrad: the first block's weight gradient assembled from R_k (the one sum over pooled elements), the input
+    moments of the forward statistics pass and the BatchNorm-backward sums — no convolution, hash or BatchNorm arithmetic is
+    redone — against a float64 autograd of conv -> BatchNorm(train) -> ReLU -> MaxPool(1,2) -> (the kernel's own dropout
+    mask), and against the recomputing apply pass it replaces.  Includes un-standardised input (mean 1.5 / -2: the closed
+    form subtracts moment terms), dropout on and off, a gamma == 0 / beta > 0 channel, and the config-1 size."""
+    gen = torch.Generator().manual_seed(B * 7 + Cin + Cc + T)
+    x = torch.randn(B, Cin, Fm, T, generator=gen) + shift
+    w = torch.randn(Cc, Cin, 3, 3, generator=gen) / np.sqrt(9 * Cin)
+    bias = torch.randn(Cc, generator=gen) * 0.3
+    gamma = torch.rand(Cc, generator=gen) + 0.5
+    beta = torch.randn(Cc, generator=gen) * 0.2
+    gamma[1], beta[1] = 0.0, 0.4
+    seed = 1234
+    out = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, drop_p=drop, seed=seed, moments_path=True)     # [B,T/2,F,C]
+    dout = torch.randn(out.shape, generator=gen) * 0.1
+    res_m = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, dout=g(dout), drop_p=drop, seed=seed, moments_path=True)
+    res_a = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, dout=g(dout), drop_p=drop, seed=seed, moments_path=False)
+    assert torch.equal(res_m[0], res_a[0])
+    # float64 reference with the kernel's own dropout mask (regenerated from the same seed through the stand-alone pass)
+    mask = torch.ones(out.shape)
+    if drop > 0:
+        ones = torch.ones(B, T, Fm, Cc).cuda()
+        mask = ops.bn_relu_pool_drop_fwd(ones, torch.ones(Cc).cuda(), torch.zeros(Cc).cuda(), 1, 2, drop_p=drop, seed=seed).cpu()
+    xd = x.double()
+    wd_ = w.double().requires_grad_(True)
+    bd = bias.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    btd = beta.double().requires_grad_(True)
+    y = F.conv2d(xd, wd_, bd, padding=1)
+    z = F.batch_norm(y, None, None, gd, btd, training=True, eps=1e-5)
+    o = F.max_pool2d(torch.relu(z), (1, 2)).permute(0, 3, 2, 1) * mask.double()          # channels-last [B,T/2,F,C]
+    o.backward(dout.double())
+    wmax = float(wd_.grad.abs().max())
+    for name, res in (("moments", res_m), ("recompute", res_a)):
+        _, dw, db, dgamma, dbeta = res
+        np.testing.assert_allclose(dw.cpu().numpy(), wd_.grad.numpy(), atol=2e-5 * wmax + 1e-6, rtol=2e-4, err_msg=name)
+        np.testing.assert_allclose(dgamma.cpu().numpy(), gd.grad.numpy(), atol=2e-5 * float(gd.grad.abs().max()) + 1e-6, rtol=2e-4, err_msg=name)
+        np.testing.assert_allclose(dbeta.cpu().numpy(), btd.grad.numpy(), atol=2e-5 * float(btd.grad.abs().max()) + 1e-6, rtol=2e-4, err_msg=name)
+        assert float(db.abs().max()) < 1e-4 * max(1.0, wmax)                         # analytically zero in front of BatchNorm
+
+
+def _conv1_fused_case(ops, B, Cin, Fm, T, Cc, pf, pt, moments):
     """first block with the conv recomputed in every pass: same results as conv -> BN(train) -> ReLU -> pool in torch"""
     gen = torch.Generator().manual_seed(B + Cin * 10 + Cc)
     x = torch.randn(B, Cin, Fm, T, generator=gen)
@@ -161,7 +209,7 @@ def test_conv1_stats_from_input_moments_vs_float64_sums(ops, cin, mu, sd):
     stat = torch.empty(1, 2, Cc, device="cuda")
     ws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, cin, T) // 4 + 1, device="cuda")
     xg = g(x)
-    check(L.sed_conv1_stats(ptr(xg), ptr(wf), ptr(g(b)), ptr(stat), ptr(ws), B, cin, Fm, T, Cc, stream_ptr()), "conv1_stats")
+    check(L.sed_conv1_stats(ptr(xg), ptr(wf), ptr(g(b)), ptr(stat), ptr(ws), B, cin, Fm, T, Cc, None, stream_ptr()), "conv1_stats")
     rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
     mean, rstd, _, _ = ops.bn_finalize_train(stat, n, torch.ones(Cc).cuda(), torch.zeros(Cc).cuda(), rm, rv)
     mean, rstd = mean.cpu().double(), rstd.cpu().double()
