@@ -377,8 +377,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int tb = blockIdx.x / nft, f0 = (blockIdx.x - tb * nft) * FT;
-    const int b = blockIdx.y, t0 = tb * TT, co0 = blockIdx.z * WROWS;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, so with the
+    // plain (x = tile, y = sequence) order the neighbours of a tile — which re-read its halo rows and columns — sit on other
+    // XCDs and every halo element comes from HBM again (1.375x the input at 8 x 20 tiles).  Launch index i = xcd + 8 j is
+    // mapped to sequence xcd + 8 (j / tiles), tile j % tiles when the batch is a multiple of 8: one sequence's tiles share an L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int id = by * (int)gridDim.x + bx, xcd = id & 7, j = id >> 3;
+        by = xcd + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+    }
+    const int tb = bx / nft, f0 = (bx - tb * nft) * FT;
+    const int b = by, t0 = tb * TT, co0 = blockIdx.z * WROWS;
     const int ct = wave % NCT, mp = wave / NCT;
     const int MROWS = TT * FT;
     const int nMT = (MROWS + 31) >> 5;
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
         }
         __syncthreads();
-        const size_t row = (size_t)b * gridDim.x + blockIdx.x;
+        const size_t row = (size_t)b * gridDim.x + bx;
         if (tid < 2 * WROWS) {
             int which = tid / WROWS, c = tid - which * WROWS;
             int cti = c >> 5, cr = c & 31;
@@ -1460,8 +1470,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
     };
 
     constexpr int BS = (NS + NB - 1) / NB;
-    int tile = blockIdx.x, cur = 0;
-    if (tile < ntiles) {                            // first tile: staged in one go
+    // a group walks a CONTIGUOUS run of tiles (consecutive time rows of one sequence): the two halo rows a tile shares with its
+    // predecessor were read by this very CU one tile earlier and come from L2 instead of HBM (a strided walk handed neighbouring
+    // tiles to workgroups on different XCDs, i.e. different L2s: PMC 1.5x the algorithmic traffic)
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    int tile = blockIdx.x * per, cur = 0;
+    const int tend = tile + per < ntiles ? tile + per : ntiles;
+    if (tile < tend) {                              // first tile: staged in one go
         origin(tile);
 #pragma unroll
         for (int k = 0; k < NS; ++k) load_item(k);
@@ -1469,9 +1484,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
         for (int k = 0; k < NS; ++k) commit_item(k, smem);
     }
     __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int nxt = tile + gridDim.x;
-        origin(nxt < ntiles ? nxt : tile);          // the last tile re-stages itself (nobody reads that image): no branch
+    for (; tile < tend; ++tile) {
+        const int nxt = tile + 1;
+        origin(nxt < tend ? nxt : tile);            // the last tile re-stages itself (nobody reads that image): no branch
         const float* buf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;       // last read before the previous barrier
         // one tile: NCH chunks of 36 MFMAs; the staging of the next tile rides along (loads before chunks 0..NB-1, commits

@@ -585,9 +585,14 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             continue;
         }
         if (s_aux) {
+            // block 0's sums came out of the data gradient just issued: finalising them is one tiny launch (16 workgroups, 10 us
+            // alone) that took 0.1-0.33 ms when it started the auxiliary chain BESIDE the MFMA weight gradient; on the main
+            // stream, before that kernel is issued, it costs its 10 us and the apply pass starts at once
+            const bool fin_on_main = L.cv[0].red_rows > 0;
+            if (fin_on_main) SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, 1, 1.f, stream));
             (void)hipEventRecord(ev_dg[0], s_main);
             (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
-            SED_TRY(bn_passes(0, aux_stream));
+            SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, fin_on_main ? 2 : 3, 1.f, aux_stream));
             if (wg0_with_bn) SED_TRY(wgrad_on(0, aux_stream));
             (void)hipEventRecord(ev_bn[0], s_aux);
         } else {
