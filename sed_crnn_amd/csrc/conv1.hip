@@ -419,8 +419,9 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
 // by the forward pass.  No conv, no hash, no BatchNorm arithmetic: 2 x 9*CIN FMAs per quad and two streamed tensors.
 // The conv-bias gradient sum_pos dy = sc [ sum g - N sg - sgx rs (sum y - N mu) ] and, for a channel with gamma == 0, dgamma
 // = rs ( b sum g + sum_k w_k R_k - mu sum g ) come out of the same sums in the assembling kernel.
+// (launch bounds: <= 85 VGPRs, so that TWO workgroups fit into the 184 registers per lane the weight gradient leaves a SIMD)
 template <int CIN>
-__global__ __launch_bounds__(256) void conv1_rgrad_k(
+__global__ __launch_bounds__(256, CIN == 1 ? 6 : 4) void conv1_rgrad_k(
     const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ pooled,
     const unsigned char* __restrict__ bits, float* __restrict__ partials, int B, int F, int T, int C, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -472,8 +473,10 @@ __global__ __launch_bounds__(256) void conv1_rgrad_k(
             }
         }
     }
-    // block reduction in fixed slot order, 5 values per round through a 20 KB buffer (as conv1_fused_k)
-    constexpr int NV = 1 + 9 * CIN, NVC = 5;
+    // block reduction in fixed slot order, ONE value per round through a 4 KB buffer: this pass runs beside the MFMA weight
+    // gradient, which leaves a CU 28 KB of LDS — with the 20 KB buffer of conv1_fused_k only one workgroup fits there (an eighth
+    // of the stand-alone occupancy: that, not issue contention, is why passes crawl beside that kernel)
+    constexpr int NV = 1 + 9 * CIN, NVC = 1;
     float* red = smem;                                        // [nslots][NVC][C]
 #pragma unroll
     for (int v0 = 0; v0 < NV; v0 += NVC) {
@@ -500,21 +503,26 @@ __global__ __launch_bounds__(256) void conv1_rgrad_k(
 __device__ __forceinline__ int c1_gidx(int k, int k2, int NK) { return NK + k * NK - (k * (k - 1)) / 2 + (k2 - k); }
 
 // one workgroup per output channel: R and sum g summed over the partial rows in fp64 (fixed order), then the closed form
-__global__ __launch_bounds__(64) void conv1_wgrad_assemble_k(
+__global__ __launch_bounds__(256) void conv1_wgrad_assemble_k(
     const float* __restrict__ part, int rows, int Cin, int C, const double* __restrict__ gram, const float* __restrict__ wp,
     const float* __restrict__ bias, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
     const float* __restrict__ sum_g, const float* __restrict__ sum_gx, double count, float* __restrict__ dw, float* __restrict__ db,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma) {
     const int co = blockIdx.x, NK = 9 * Cin, NV = 1 + NK;
     __shared__ double sv[37];                                 // [0] sum g, [1..NK] R_k
-    const int lane = threadIdx.x;
-    for (int v = 0; v < NV; ++v) {
+    __shared__ double sw[4][37];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int v = 0; v < NV; ++v) {                            // 256 row slices, 8 independent loads in flight per thread
         double a = 0.0;
-        for (int r = lane; r < rows; r += 64) a += (double)part[((size_t)r * NV + v) * C + co];
+#pragma unroll 8
+        for (int r = threadIdx.x; r < rows; r += 256) a += (double)part[((size_t)r * NV + v) * C + co];
         a = wave_sum_d(a);
-        if (lane == 0) sv[v] = a;
+        if (lane == 0) sw[wv][v] = a;
     }
     __syncthreads();
+    if (threadIdx.x < NV) sv[threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
+    __syncthreads();
+    if (wv != 0) return;
     const double b = bias ? (double)bias[co] : 0.0, mu = mean[co], rs = rstd[co], sc = scale[co];
     const double sg = (double)sum_g[co] / count, sgx = (double)sum_gx[co] / count;
     if (lane < NK) {
@@ -679,8 +687,13 @@ extern "C" int sed_conv1_rgrad_supported(int Cin, int F, int T, int C, int pf, i
     return sed_conv1_fused_supported(Cin, F, T, C, pf, pt) && pf == 1 && pt == 2;
 }
 extern "C" size_t sed_conv1_moments_doubles(int Cin) { const int nk = 9 * Cin; return (size_t)nk + (size_t)nk * (nk + 1) / 2; }
+// partial rows of conv1_rgrad_k: two persistent workgroups per CU are plenty for a streaming pass, and the assembling kernel
+// that sums them runs beside an MFMA kernel, where every row costs
+static int c1_rgrad_rows(int B, int T) {          // (512 rows instead of 2048: the pass beside the weight gradient 1.14 -> 1.58 ms)
+    return sed_conv1_fused_rows(B, T);
+}
 extern "C" size_t sed_conv1_bwd_wgrad_workspace_bytes(int B, int Cin, int T, int C) {
-    return (size_t)sed_conv1_fused_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
+    return (size_t)c1_rgrad_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
 }
 extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const float* pooled, const unsigned char* argmax_bits,
                                    const double* moments, const float* wp, const float* bias, const float* mean, const float* rstd,
@@ -693,8 +706,9 @@ extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const floa
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_bwd_wgrad: drop_p=%f out of [0,1)", drop_p);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_BWD_APPLY, s, 2.0 * 4.0 * B * C * (double)(T / 2) * F);
-    const size_t lds = c1_lds(Cin, F, C, 3);
-    const int grid = sed_conv1_fused_rows(B, T);
+    size_t lds = (size_t)(C1_TT + 2) * (F + 2) * Cin * sizeof(float);      // halo tile, or the one-value reduction buffer
+    if (lds < (size_t)256 * 4 * sizeof(float)) lds = (size_t)256 * 4 * sizeof(float);
+    const int grid = c1_rgrad_rows(B, T);
     const float inv_keep = 1.f / (1.f - drop_p);
     if (Cin == 1) {
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -704,7 +718,7 @@ extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const floa
         conv1_rgrad_k<2><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
     }
     SED_LAUNCH_CHECK("conv1_rgrad");
-    conv1_wgrad_assemble_k<<<C, 64, 0, s>>>((const float*)workspace, grid, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
+    conv1_wgrad_assemble_k<<<C, 256, 0, s>>>((const float*)workspace, grid, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
                                            (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);
     SED_LAUNCH_CHECK("conv1_wgrad_assemble");
     return 0;

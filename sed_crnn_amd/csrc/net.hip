@@ -78,11 +78,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->bn_sums[l] = cv.take((size_t)2 * q.C);
         if (npool > max_pool) max_pool = npool;
         if (q.fused) {
-            // The moment-based backward (sed_conv1_bwd_wgrad: no recompute, 2.7x fewer vector instructions) is NOT used by the plan
-            // for now: measured at config 2 it runs 1.14 ms beside the MFMA weight gradient where the recomputing pass runs 1.44,
-            // but its two small companions (finalise 0.33, assemble 0.15 beside) put the tail at 0.28 ms against 0.11 — an HBM- or
-            // VALU-bound kernel beside a persistent MFMA kernel advances at ~1/8 of its rate whatever it does.  Kept as an entry.
-            q.rgrad = 0;
+            // the (1,2)-pooled block takes the moment-based backward (sed_conv1_bwd_wgrad: nothing is recomputed)
+            q.rgrad = training && sed_conv1_rgrad_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt) ? 1 : 0;
             c1_ws = sed_conv1_bwd_apply_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
             const size_t w2 = sed_conv1_bwd_wgrad_workspace_bytes(c->B, q.Cin, q.T, q.C) / sizeof(float);
             if (w2 > c1_ws) c1_ws = w2;
