@@ -407,6 +407,119 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
     }
 }
 
+// ── input moments for 3 or 4 input channels (config 5: 4-channel input) ──
+// conv1_gram_k keeps all NK + NK(NK+1)/2 accumulators of a thread in registers: 54 at one channel, 189 at two, 702 at four.
+// Here the second-moment matrix is cut into row blocks of C1_KB taps (blockIdx.y): a thread accumulates S1 of its C1_KB taps and
+// their products with ALL NK taps (the full rows; the finalisation reads the upper triangle), C1_KB * (NK + 1) <= 148 registers.
+// Every tap value read from LDS feeds C1_KB FMAs.  Partials [nblk][NKB][C1_KB][NK + 1] fp32, summed in fp64 in a fixed order.
+#define C1_KB 4
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_moments_k(const float* __restrict__ x, float* __restrict__ partials, int B, int F, int T) {
+    constexpr int NK = 9 * CIN, NKB = (NK + C1_KB - 1) / C1_KB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2;
+    float* halo = smem;                                       // [(GT+2)][F2][CIN]
+    const int tid = threadIdx.x, kb = blockIdx.y, k0 = kb * C1_KB;
+    const int tblocks = (T + C1_GT - 1) / C1_GT, ntiles = B * tblocks;
+    // LDS offsets of this row block's own taps (k = tap * CIN + ci, tap = kh * 3 + kw), relative to a position's halo origin
+    int aoff[C1_KB];
+#pragma unroll
+    for (int a = 0; a < C1_KB; ++a) {
+        const int k = (k0 + a < NK) ? k0 + a : NK - 1, tap = k / CIN, ci = k - tap * CIN, kh = tap / 3, kw = tap - kh * 3;
+        aoff[a] = (kw * F2 + kh) * CIN + ci;
+    }
+    float acc[C1_KB][NK + 1];
+#pragma unroll
+    for (int a = 0; a < C1_KB; ++a)
+#pragma unroll
+        for (int i = 0; i <= NK; ++i) acc[a][i] = 0.f;
+    const int hn = (C1_GT + 2) * F2 * CIN;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tblocks, t0 = (tile - b * tblocks) * C1_GT;
+        __syncthreads();
+        for (int j = tid; j < hn; j += 256) {                 // time fastest: contiguous in the NCHW input
+            int tt = j % (C1_GT + 2), ff = (j / (C1_GT + 2)) % F2, ci = j / ((C1_GT + 2) * F2);
+            const int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * CIN + ci) * F + f) * T + t];
+            halo[(tt * F2 + ff) * CIN + ci] = v;
+        }
+        __syncthreads();
+        for (int q = tid; q < C1_GT * F; q += 256) {
+            const int tl = q / F, f = q - tl * F;
+            if (t0 + tl >= T) continue;
+            const float* hp = halo + (tl * F2 + f) * CIN;
+            float va[C1_KB];
+#pragma unroll
+            for (int a = 0; a < C1_KB; ++a) { va[a] = hp[aoff[a]]; acc[a][0] += va[a]; }
+            // only the columns k2 >= k0 are kept (upper triangle): the block-uniform test skips the others' FMAs
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const int k2 = (kh * 3 + kw) * CIN + ci;
+                        if (k2 >= k0) {
+                            const float v2 = hp[(kw * F2 + kh) * CIN + ci];
+#pragma unroll
+                            for (int a = 0; a < C1_KB; ++a) acc[a][1 + k2] += va[a] * v2;
+                        }
+                    }
+        }
+    }
+    __syncthreads();
+    float* red = smem;                                         // [4] per value
+    const int lane = tid & 63, wave = tid >> 6;
+    float* dst = partials + ((size_t)blockIdx.x * NKB + kb) * C1_KB * (NK + 1);
+#pragma unroll
+    for (int a = 0; a < C1_KB; ++a)
+#pragma unroll
+        for (int i = 0; i <= NK; ++i) {
+            const float sum = wave_sum(acc[a][i]);
+            if (lane == 0) red[(a * (NK + 1) + i) * 4 + wave] = sum;
+        }
+    __syncthreads();
+    for (int i = tid; i < C1_KB * (NK + 1); i += 256)
+        dst[i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+}
+
+// moments in fp64, packed like conv1_gram_k's (S1, then the upper triangle row by row): one workgroup per tap row, 64 lanes
+// over the partial rows of each entry
+template <int CIN>
+__global__ __launch_bounds__(64) void conv1_moments_sum_k(const float* __restrict__ partials, int nblk, double* __restrict__ gram_out) {
+    constexpr int NK = 9 * CIN, NKB = (NK + C1_KB - 1) / C1_KB, ROW = NK + 1;
+    const int k = blockIdx.x, kb = k / C1_KB, a = k - kb * C1_KB, lane = threadIdx.x;
+    for (int i = 0; i < ROW; ++i) {
+        if (i > 0 && i - 1 < k) continue;                      // lower triangle: not kept
+        double sum = 0.0;
+        for (int r = lane; r < nblk; r += 64) sum += (double)partials[(((size_t)r * NKB + kb) * C1_KB + a) * ROW + i];
+        sum = wave_sum_d(sum);
+        if (lane == 0) gram_out[i == 0 ? k : NK + k * NK - (k * (k - 1)) / 2 + (i - 1 - k)] = sum;
+    }
+}
+
+// the statistics row (sum y, sum y^2 per channel) from the moments: fp64 quadratic form
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_moments_stat_k(const double* __restrict__ G, const float* __restrict__ wp,
+                                                            const float* __restrict__ bias, double count, int C, float* __restrict__ stat) {
+    constexpr int NK = 9 * CIN;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double b = bias ? (double)bias[c] : 0.0;
+    double ws1 = 0.0, q = 0.0;
+    for (int k = 0; k < NK; ++k) {
+        const double wk = (double)wp[((size_t)(k / CIN) * C + c) * CIN + (k % CIN)];
+        ws1 += wk * G[k];
+        for (int k2 = k; k2 < NK; ++k2) {
+            const double wk2 = (double)wp[((size_t)(k2 / CIN) * C + c) * CIN + (k2 % CIN)];
+            q += (k2 == k ? 1.0 : 2.0) * wk * wk2 * G[NK + k * NK - (k * (k - 1)) / 2 + (k2 - k)];
+        }
+    }
+    stat[c] = (float)(count * b + ws1);
+    stat[C + c] = (float)(q + 2.0 * b * ws1 + count * b * b);
+}
+
 // ── backward of the recomputed block WITHOUT recomputing it (round 3) ──
 // The old apply pass (MODE 3) recomputes both conv outputs of every window, the dropout hash and BatchNorm, forms dy for both
 // rows and accumulates 2 x 9*CIN taps: ~240 vector instructions per output quad, and beside the MFMA weight gradients (where it
@@ -421,7 +534,7 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
 // = rs ( b sum g + sum_k w_k R_k - mu sum g ) come out of the same sums in the assembling kernel.
 // (launch bounds: <= 85 VGPRs, so that TWO workgroups fit into the 184 registers per lane the weight gradient leaves a SIMD)
 template <int CIN>
-__global__ __launch_bounds__(256, CIN == 1 ? 6 : 4) void conv1_rgrad_k(
+__global__ __launch_bounds__(256, CIN == 1 ? 6 : (CIN == 2 ? 4 : 2)) void conv1_rgrad_k(
     const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ pooled,
     const unsigned char* __restrict__ bits, float* __restrict__ partials, int B, int F, int T, int C, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -558,8 +671,12 @@ static size_t c1_lds(int Cin, int F, int C, int mode) {
     return halo > red ? halo : red;
 }
 
+static int c1_shape_ok(int Cin, int F, int T, int C, int pool_f, int pool_t, int max_cin);
 extern "C" int sed_conv1_fused_supported(int Cin, int F, int T, int C, int pool_f, int pool_t) {
-    if (Cin < 1 || Cin > 2 || C < 4 || F < 1 || T < 1 || C % 4 != 0 || C / 4 > 256 || (256 % (C / 4)) != 0) return 0;
+    return c1_shape_ok(Cin, F, T, C, pool_f, pool_t, 2);
+}
+static int c1_shape_ok(int Cin, int F, int T, int C, int pool_f, int pool_t, int max_cin) {
+    if (Cin < 1 || Cin > max_cin || C < 4 || F < 1 || T < 1 || C % 4 != 0 || C / 4 > 256 || (256 % (C / 4)) != 0) return 0;
     if (pool_t < 1 || pool_f < 1 || C1_TT % pool_t != 0 || T % C1_TT != 0 || F % pool_f != 0 || T % pool_t != 0) return 0;
     if (c1_lds(Cin, F, C, 3) > 150 * 1024) return 0;
     return 1;
@@ -586,7 +703,14 @@ static int c1_launch(const float* x, const float* wp, const float* bias, const f
                                                               partials, B, F, T, C, pf, pt, drop_p, seed, seed_dev);  \
     } while (0)
     if (Cin == 1) { if (p12) C1_LAUNCH(1, true); else C1_LAUNCH(1, false); }
-    else { if (p12) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
+    else if (Cin == 2) { if (p12) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
+    else if (MODE == 1 && p12) {           // 3 / 4 input channels: the forward pass only (statistics from the blocked moment
+        if (Cin == 3) C1_LAUNCH(3, true);  // kernel, backward through sed_conv3x3_dgrad_bnred + sed_conv1_bwd_wgrad)
+        else C1_LAUNCH(4, true);
+    } else {
+        sed_set_error("conv1: %d input channels are supported by the forward pass with the (1,2) pool only", Cin);
+        return SED_EUNSUPPORTED;
+    }
 #undef C1_LAUNCH
     return 0;
 }
@@ -597,16 +721,40 @@ static int c1_launch(const float* x, const float* wp, const float* bias, const f
 
 extern "C" size_t sed_conv1_stats_workspace_bytes(int B, int Cin, int T) {
     const int nk = 9 * Cin;
+    if (Cin > 2) return (size_t)256 * ((nk + C1_KB - 1) / C1_KB) * C1_KB * (nk + 1) * sizeof(float) + (size_t)(nk + nk * (nk + 1) / 2) * sizeof(double);
     return (size_t)256 * (nk + nk * (nk + 1) / 2) * sizeof(float);      // at most 256 partial rows (one per workgroup)
 }
 
 extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bias, float* stat_partials, void* workspace,
                                int B, int Cin, int F, int T, int C, double* gram_out, void* stream) {
     SED_REQUIRE(x && wp && stat_partials && workspace, "conv1_stats: null pointer");
-    const int pf = 1, pt = 1;
-    C1_CHECK("conv1_stats");
+    SED_REQUIRE(c1_shape_ok(Cin, F, T, C, 1, 1, 4), "conv1_stats: shape Cin=%d F=%d T=%d C=%d is not supported", Cin, F, T, C);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_CONV_SMALL_FWD, s, 4.0 * B * Cin * (double)F * T);
+    if (Cin > 2) {
+        const int nk = 9 * Cin, nkb = (nk + C1_KB - 1) / C1_KB;
+        int nb = B * ((T + C1_GT - 1) / C1_GT);
+        if (nb > 256) nb = 256;
+        size_t lds = (size_t)(C1_GT + 2) * (F + 2) * Cin * sizeof(float), red = (size_t)C1_KB * (nk + 1) * 4 * sizeof(float);
+        if (red > lds) lds = red;
+        SED_REQUIRE(lds <= 150 * 1024, "conv1_stats: F=%d Cin=%d needs %zu B of LDS", F, Cin, lds);
+        const double cnt = (double)B * T * F;
+        // the fp64 moments go to the caller's array, or behind the partial rows in the workspace when the caller does not want them
+        double* G = gram_out ? gram_out : (double*)((float*)workspace + (size_t)256 * nkb * C1_KB * (nk + 1));
+#define C1_MOM(CIN_)                                                                                                              \
+    do {                                                                                                                          \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_moments_k<CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        conv1_moments_k<CIN_><<<dim3(nb, nkb), 256, lds, s>>>(x, (float*)workspace, B, F, T);                                       \
+        conv1_moments_sum_k<CIN_><<<nk, 64, 0, s>>>((const float*)workspace, nb, G);                                               \
+        conv1_moments_stat_k<CIN_><<<cdiv(C, 256), 256, 0, s>>>(G, wp, bias, cnt, C, stat_partials);                               \
+    } while (0)
+        if (Cin == 3) C1_MOM(3); else C1_MOM(4);
+#undef C1_MOM
+        SED_LAUNCH_CHECK("conv1_moments");
+        return 0;
+    }
+    const int pf = 1, pt = 1;
+    C1_CHECK("conv1_stats");
     int grid = (B * ((T + C1_GT - 1) / C1_GT) + C1_GR - 1) / C1_GR;
     if (grid > 256) grid = 256;                              // one workgroup per CU; at most 256 partial rows for the finalisation
     const int nk = 9 * Cin, ng = nk + nk * (nk + 1) / 2;
@@ -637,11 +785,12 @@ extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, 
                                                unsigned char* argmax_bits, void* stream) {
     SED_REQUIRE(x && wp && scale && shift && out, "conv1_fwd: null pointer");
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_fwd: drop_p=%f out of [0,1)", drop_p);
-    C1_CHECK("conv1_fwd");
+    SED_REQUIRE(c1_shape_ok(Cin, F, T, C, pf, pt, (pf == 1 && pt == 2) ? 4 : 2), "conv1_fwd: shape Cin=%d F=%d T=%d C=%d pool=(%d,%d) is not "
+                "supported by the fused first block", Cin, F, T, C, pf, pt);
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_BN_FWD, s, 4.0 * B * C * (double)(T / pt) * (F / pf));
     SED_REQUIRE(!argmax_bits || (pf == 1 && pt == 2), "conv1_fwd: arg-max bits exist for the (1,2) pool only");
-    c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, reinterpret_cast<float*>(argmax_bits), B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s);
+    SED_TRY(c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, reinterpret_cast<float*>(argmax_bits), B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s));
     SED_LAUNCH_CHECK("conv1_fwd");
     return 0;
 }
@@ -684,7 +833,7 @@ extern "C" int sed_conv1_bwd_apply_wgrad(const float* x, const float* wp, const 
 
 // ── the backward of the recomputed block from its pooled output, arg-max bits and input moments (see conv1_rgrad_k) ──
 extern "C" int sed_conv1_rgrad_supported(int Cin, int F, int T, int C, int pf, int pt) {
-    return sed_conv1_fused_supported(Cin, F, T, C, pf, pt) && pf == 1 && pt == 2;
+    return pf == 1 && pt == 2 && c1_shape_ok(Cin, F, T, C, pf, pt, 4);
 }
 extern "C" size_t sed_conv1_moments_doubles(int Cin) { const int nk = 9 * Cin; return (size_t)nk + (size_t)nk * (nk + 1) / 2; }
 // partial rows of conv1_rgrad_k: two persistent workgroups per CU are plenty for a streaming pass, and the assembling kernel
@@ -710,13 +859,18 @@ extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const floa
     if (lds < (size_t)256 * 4 * sizeof(float)) lds = (size_t)256 * 4 * sizeof(float);
     const int grid = c1_rgrad_rows(B, T);
     const float inv_keep = 1.f / (1.f - drop_p);
-    if (Cin == 1) {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_rgrad_k<1><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
-    } else {
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        conv1_rgrad_k<2><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
+#define C1_RGRAD(CIN_)                                                                                                        \
+    do {                                                                                                                      \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        conv1_rgrad_k<CIN_><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);    \
+    } while (0)
+    switch (Cin) {
+        case 1: C1_RGRAD(1); break;
+        case 2: C1_RGRAD(2); break;
+        case 3: C1_RGRAD(3); break;
+        default: C1_RGRAD(4); break;
     }
+#undef C1_RGRAD
     SED_LAUNCH_CHECK("conv1_rgrad");
     conv1_wgrad_assemble_k<<<C, 256, 0, s>>>((const float*)workspace, grid, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
                                            (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);

@@ -60,6 +60,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         q.Tp = T / q.pt; q.Fp = F / q.pf;
         // block 1 with <= 2 input channels: the conv output is recomputed in every pass and never stored (conv1.hip)
         q.fused = (l == 0 && c->n_conv > 1 && sed_conv1_fused_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt)) ? 1 : 0;
+        // 3 or 4 input channels (config 5): recomputed as well when the whole moment-based chain is available — statistics from
+        // the blocked moment kernel, (1,2) pool, and the data gradient of block 1 on the MFMA path (it forms this block's
+        // BatchNorm-backward sums; the recomputing reduce / apply passes do not exist beyond 2 channels)
+        if (l == 0 && !q.fused && c->n_conv > 1 && q.Cin <= 4 && c->conv_mode == 0 &&
+            sed_conv1_rgrad_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt) &&
+            sed_conv3x3_dgrad_bnred_rows(c->B, c->C[1], q.F / q.pf, q.T / q.pt, q.C) > 0)
+            q.fused = 1;
         if (q.fused) {
             q.rows = 1;                                        // statistics from the input moments: one partial row
             q.bn_rows = sed_conv1_fused_rows(c->B, q.T);

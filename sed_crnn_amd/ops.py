@@ -254,7 +254,7 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
     B, Cin, F, T = x.shape
     Cc = w.shape[0]
     L = lib()
-    assert L.sed_conv1_fused_supported(Cin, F, T, Cc, pool_f, pool_t)
+    assert L.sed_conv1_fused_supported(Cin, F, T, Cc, pool_f, pool_t) or (moments_path and L.sed_conv1_rgrad_supported(Cin, F, T, Cc, pool_f, pool_t))
     wf, _ = conv3x3_pack(w)
     rows = L.sed_conv1_fused_rows(B, T)
     stat = torch.empty(1, 2, Cc, device=x.device)
@@ -269,11 +269,18 @@ def conv1_fused_block(x, w, bias, gamma, beta, pool_f, pool_t, dout=None, drop_p
                                             pool_f, pool_t, drop_p, seed, None, ptr(bits), stream_ptr()), "conv1_fwd")
     if dout is None:
         return out
-    part = torch.empty(rows, 2, Cc, device=x.device)
-    check(L.sed_conv1_bwd_reduce(ptr(x), ptr(wf), ptr(bias), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
-                                 ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_bwd_reduce")
     sum_g, sum_gx, dgamma, dbeta = (torch.empty(Cc, device=x.device) for _ in range(4))
-    check(L.sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta), stream_ptr()), "bn_bwd_finalize")
+    if Cin <= 2:
+        part = torch.empty(rows, 2, Cc, device=x.device)
+        check(L.sed_conv1_bwd_reduce(ptr(x), ptr(wf), ptr(bias), ptr(_f32c(dout)), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                                     ptr(part), B, Cin, F, T, Cc, pool_f, pool_t, drop_p, seed, None, stream_ptr()), "conv1_bwd_reduce")
+        check(L.sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), ptr(dgamma), ptr(dbeta), stream_ptr()), "bn_bwd_finalize")
+    else:
+        # beyond two input channels there is no recomputing reduce pass (in the network these sums come out of the data gradient
+        # of the block above): here the conv output is materialised once and reduced by the stand-alone pass
+        y, _ = conv3x3_fwd(x, wf, bias, True, want_stats=False)
+        _, dgamma, dbeta, _ = bn_relu_pool_drop_bwd(y, _f32c(dout), scale, shift, mean, rstd, pool_f, pool_t, drop_p=drop_p, seed=seed)
+        sum_g, sum_gx = dbeta.clone(), dgamma.clone()
     dw, db = torch.empty_like(w), torch.empty(Cc, device=x.device)
     if moments_path:
         assert L.sed_conv1_rgrad_supported(Cin, F, T, Cc, pool_f, pool_t)

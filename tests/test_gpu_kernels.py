@@ -121,7 +121,8 @@ def test_conv1_fused_block_vs_torch(ops, B, Cin, Fm, T, Cc, pf, pt):
 
 
 @pytest.mark.parametrize("B,Cin,Fm,T,Cc,drop,shift", [(2, 1, 40, 16, 8, 0.0, 0.0), (3, 1, 40, 8, 128, 0.5, 0.0), (2, 2, 40, 8, 128, 0.3, 0.0),
-                                                      (4, 1, 40, 64, 128, 0.5, 1.5), (2, 2, 24, 12, 32, 0.0, -2.0), (16, 1, 40, 256, 128, 0.5, 0.0)])
+                                                      (4, 1, 40, 64, 128, 0.5, 1.5), (2, 2, 24, 12, 32, 0.0, -2.0), (16, 1, 40, 256, 128, 0.5, 0.0),
+                                                      (2, 4, 128, 16, 128, 0.5, 0.0), (3, 3, 40, 8, 32, 0.0, 1.0), (2, 4, 128, 64, 128, 0.5, -1.5)])
 def test_conv1_backward_from_pooled_output_bits_and_moments_vs_float64(ops, B, Cin, Fm, T, Cc, drop, shift):
     """sed_conv1_bwd_wgrad: the first block's weight gradient assembled from R_k (the one sum over pooled elements), the input
     moments of the forward statistics pass and the BatchNorm-backward sums — no convolution, hash or BatchNorm arithmetic is
@@ -139,8 +140,11 @@ def test_conv1_backward_from_pooled_output_bits_and_moments_vs_float64(ops, B, C
     out = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, drop_p=drop, seed=seed, moments_path=True)     # [B,T/2,F,C]
     dout = torch.randn(out.shape, generator=gen) * 0.1
     res_m = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, dout=g(dout), drop_p=drop, seed=seed, moments_path=True)
-    res_a = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, dout=g(dout), drop_p=drop, seed=seed, moments_path=False)
-    assert torch.equal(res_m[0], res_a[0])
+    both = [("moments", res_m)]
+    if Cin <= 2:                      # the recomputing passes exist for one and two input channels only
+        res_a = ops.conv1_fused_block(g(x), g(w), g(bias), g(gamma), g(beta), 1, 2, dout=g(dout), drop_p=drop, seed=seed, moments_path=False)
+        assert torch.equal(res_m[0], res_a[0])
+        both.append(("recompute", res_a))
     # float64 reference with the kernel's own dropout mask (regenerated from the same seed through the stand-alone pass)
     mask = torch.ones(out.shape)
     if drop > 0:
@@ -156,7 +160,8 @@ def test_conv1_backward_from_pooled_output_bits_and_moments_vs_float64(ops, B, C
     o = F.max_pool2d(torch.relu(z), (1, 2)).permute(0, 3, 2, 1) * mask.double()          # channels-last [B,T/2,F,C]
     o.backward(dout.double())
     wmax = float(wd_.grad.abs().max())
-    for name, res in (("moments", res_m), ("recompute", res_a)):
+    np.testing.assert_allclose(res_m[0].cpu().numpy(), o.detach().numpy(), atol=3e-5, rtol=1e-4)
+    for name, res in both:
         _, dw, db, dgamma, dbeta = res
         np.testing.assert_allclose(dw.cpu().numpy(), wd_.grad.numpy(), atol=2e-5 * wmax + 1e-6, rtol=2e-4, err_msg=name)
         np.testing.assert_allclose(dgamma.cpu().numpy(), gd.grad.numpy(), atol=2e-5 * float(gd.grad.abs().max()) + 1e-6, rtol=2e-4, err_msg=name)
