@@ -447,6 +447,7 @@ enum sed_kernel_tag {
     SED_K_GRU_BWD,             /* units: FLOPs */
     SED_K_ADAM,                /* units: bytes */
     SED_K_LOGMEL,              /* units: bytes (hop*4 read + n_mels*4 written per frame) */
+    SED_K_CONV_MFMA_DGRAD,     /* units: FLOPs — sed_conv3x3_dgrad_bnred (the forward kernel with the BatchNorm-backward epilogue) */
     SED_K_COUNT
 };
 int sed_prof_enable(unsigned tag_mask);

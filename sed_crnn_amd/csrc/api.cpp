@@ -32,7 +32,7 @@ hipEvent_t get_event() {
 }
 const char* kNames[SED_K_COUNT] = {"conv3x3_mfma_fwd", "conv3x3_small_fwd", "conv3x3_mfma_wgrad", "conv3x3_small_wgrad",
                                    "bn_relu_pool_drop_fwd", "bn_bwd_reduce", "bn_bwd_apply", "gemm_f32", "gru_seq_fwd",
-                                   "gru_seq_bwd", "adam", "logmel"};
+                                   "gru_seq_bwd", "adam", "logmel", "conv3x3_mfma_dgrad_bnred"};
 }  // namespace
 
 void sed_prof_begin(int tag, hipStream_t s, double units) {

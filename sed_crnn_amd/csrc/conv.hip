@@ -980,7 +980,7 @@ extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, f
         return -1;
     }
     hipStream_t s = as_stream(stream);
-    SedProfScope prof(SED_K_CONV_MFMA_FWD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
+    SedProfScope prof(SED_K_CONV_MFMA_DGRAD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
     ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty};
     dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
     SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
