@@ -79,6 +79,7 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
         p.lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
         const size_t epi = (size_t)(4 * 1024 + 256) * sizeof(float);      // epilogue: four 32x32 transpose scratches + the stat exchange
         if (p.lds < epi) p.lds = epi;
+        p.lds += (size_t)limit * sizeof(unsigned);                        // the epilogue's row-offset table (one entry per MFMA row)
     }
     if (p.kind < 0) {
         if (Cout % 4 != 0) return p;
@@ -362,7 +363,7 @@ template <int NCT, int MINW, bool BNR = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft,
-    ConvBnRed br = ConvBnRed{}) {
+    float invF, float invF2, ConvBnRed br = ConvBnRed{}) {
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // so every ds_read_b128 lane group stays conflict-free (PMC: 35 % bank-conflict cycles without it).
     const int TP = F2 * CV_LD + CV_TPAD;
     const int HB = (TT + 2) * TP;
-    const float invF = 1.0f / (float)FT, invF2 = 1.0f / (float)F2;
+    // invF = 1 / FT, invF2 = 1 / (FT + 2) come from the host (sed_fdiv's reciprocals: two float divisions fewer per lane)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -402,11 +403,27 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         int tl = sed_fdiv(p, invF), f = p - tl * FT;
         abase[i] = tl * TP + f * CV_LD + 4 * h;
     }
+    // Accumulators start at the bias: a register holds one output channel (lane r) of 16 rows, so the epilogue has no add left.
+    const float bv = bias ? bias[co0 + ct * 32 + r] : 0.f;
     f32x16 acc[CV_MTW];
 #pragma unroll
     for (int i = 0; i < CV_MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        for (int j = 0; j < 16; ++j) acc[i][j] = bv;
+
+    // Row-offset table of the epilogue, behind the halo buffers and the transpose scratch: entry [mt][rq][k] = byte offset of
+    // output row p = 32 mt + rq + 8 k inside sequence b (all Cout channels of one position), ~0 for a row outside the output.
+    // Computed once per workgroup here instead of once per lane and store there: while the co-resident workgroup is in its
+    // MFMA loop (fp32 MFMAs occupy the VALU) this workgroup's vector instructions issue at about one per MFMA, so the
+    // epilogue's duration IS its VALU instruction count x 64 cycles (measured with s_memrealtime stamps: 850 VALU instructions,
+    // 22 us per workgroup, against 3.4 us with the CU to itself) — address arithmetic was half of them.
+    unsigned* rowtab = (unsigned*)(smem + (2 * HB > 4 * 1024 + 256 ? 2 * HB : 4 * 1024 + 256));
+    for (int sidx = tid; sidx < nMT * 32; sidx += 256) {
+        const int p = (sidx & ~31) + ((sidx >> 2) & 7) + 8 * (sidx & 3);
+        const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+        const bool ok = p < MROWS && t0 + tl < T && f < F;
+        rowtab[sidx] = ok ? (unsigned)(((t0 + tl) * F + f) * Cout) * 4u : 0xFFFFFFFFu;
+    }
 
     // Halo staging.  Every lane issues all CV_NH loads of a chunk from a clamped (always valid) address and zeroes the
     // out-of-range ones when it commits them: a fixed number of load instructions per chunk is what lets the hand-counted
@@ -521,15 +538,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // 4 KB of the (now free) halo buffer: 16 ds_write_b32, then 4 ds_read_b128 give every lane 4 consecutive channels of a
     // row, and the tile leaves in 4 global_store_dwordx4 per lane (8 full 128-byte rows per instruction).  A 32-float row
     // stride is conflict-free for both the b32 writes and the b128 lane groups.
-    const int co = co0 + ct * 32 + r;
-    const float bv = bias ? bias[co] : 0.f;
+    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
     float s1 = 0.f, s2 = 0.f;
     float* tsc = smem + wave * 1024;                 // the last loop barrier already passed: the halo buffers are free
     const int rq = lane >> 3, c4 = (lane & 7) * 4;
     // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
     const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
-    // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3)
-    f32x4 q_beta = {0, 0, 0, 0}, q_rg = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    // wave-uniform base of this wave's 32 channels in sequence b; a lane adds its row offset (table) and 4 c4 bytes
+    char* const yb = (char*)(y + (size_t)b * T * F * Cout + co0 + ct * 32);
+    const char* const qb = BNR ? (const char*)(br.pooled + (size_t)b * T * F * Cout + co0 + ct * 32) : nullptr;
+    // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3):
+    // xhat = q (1-p)/gamma - beta/gamma = q * q_kr + q_nb
+    f32x4 q_beta = {0, 0, 0, 0}, q_rg = {0, 0, 0, 0}, q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     unsigned slowmask = 0;                           // bit e: gamma == 0 and beta > 0 (xhat from the conv output)
     if (BNR) {
         const int cb = co0 + ct * 32 + c4;
@@ -538,42 +558,49 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             q_rg[e] = gm[e] != 0.f ? 1.0f / gm[e] : 0.f;
+            q_kr[e] = br.keep * q_rg[e];
+            q_nb[e] = -q_beta[e] * q_rg[e];
             if (gm[e] == 0.f && q_beta[e] > 0.f) slowmask |= 1u << e;
         }
     }
+    const bool anyslow = BNR && __builtin_amdgcn_ballot_w64(slowmask != 0) != 0;     // wave-uniform, measure zero
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto store_tiles = [&](auto checked) {
         constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
         for (int i = 0; i < CV_MTW; ++i) {
             int mt = mp + i * MPARTS;
             if (mt < nMT) {
+                const u32x4 rr = *(const u32x4*)(rowtab + mt * 32 + rq * 4);              // rows rq + 8 k of this tile
+                const u32x4 ro = rr + (unsigned)(c4 * 4);
                 // BNR: this tile's pooled values, requested before the transpose so that they arrive under it
                 f32x4 pq[4];
                 if (BNR) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int p = mt * 32 + rq + 8 * k;
-                        const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                        const bool ok = !CHK || (p < MROWS && t0 + tl < T && f < F);
                         pq[k] = (f32x4){0, 0, 0, 0};
-                        if (ok) pq[k] = *(const f32x4*)(br.pooled + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4);
+                        if (!CHK || rr[k] != 0xFFFFFFFFu) pq[k] = *(const f32x4*)(qb + ro[k]);
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-                    float v = acc[i][j] + bv;
-                    tsc[row * 32 + r] = v;
-                    if (!BNR) {
-                        bool ok = true;
-                        if (CHK) {
-                            int p = mt * 32 + row;
-                            int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                            ok = p < MROWS && t0 + tl < T && f < F;
+                for (int j = 0; j < 16; ++j) tsc[((j & 3) + 8 * (j >> 2) + 4 * h) * 32 + r] = acc[i][j];
+                if (!BNR) {
+                    if (!CHK) {
+#pragma unroll
+                        for (int j = 0; j < 16; j += 2) {
+                            const f32x2 v = {acc[i][j], acc[i][j + 1]};
+                            s1v += v;
+                            s2v += v * v;
                         }
-                        if (ok) {
-                            s1 += v;
-                            s2 += v * v;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            const int p = mt * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+                            const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+                            if (p < MROWS && t0 + tl < T && f < F) {
+                                s1 += acc[i][j];
+                                s2 += acc[i][j] * acc[i][j];
+                            }
                         }
                     }
                 }
@@ -581,28 +608,36 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    int row = rq + 8 * k;
-                    int p = mt * 32 + row;
-                    int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-                    f32x4 v = *(const f32x4*)(tsc + row * 32 + c4);
-                    const bool ok = !CHK || (p < MROWS && t0 + tl < T && f < F);
-                    if (ok) *(f32x4*)(y + (((size_t)b * T + t0 + tl) * F + f) * Cout + co0 + ct * 32 + c4) = v;
+                    const f32x4 v = *(const f32x4*)(tsc + (rq + 8 * k) * 32 + c4);
+                    const bool ok = !CHK || rr[k] != 0xFFFFFFFFu;
+                    if (ok) *(f32x4*)(yb + ro[k]) = v;
                     if (BNR && ok) {
+                        if (!anyslow) {
+                            // g = v / (1-p) where the pooled value is > 0; the 1 / (1-p) is applied to the sums at the end
+                            f32x4 g0;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pv = pq[k][e];
-                            const float g = pv > 0.f ? v[e] * br.inv_keep : 0.f;
-                            float xh = (pv * br.keep - q_beta[e]) * q_rg[e];
-                            if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
-                                const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
-                                xh = 0.f;                 // (no stored conv output: the block's own apply pass supplies this dgamma)
-                                if (br.ybelow) {
-                                    const float yv = br.ybelow[(((size_t)b * br.Ty + (size_t)(t0 + tl) * br.pt) * br.Fy + (size_t)f * br.pf) * Cout + cc];
-                                    xh = (yv - br.mean[cc]) * br.rstd[cc];
+                            for (int e = 0; e < 4; ++e) g0[e] = pq[k][e] > 0.f ? v[e] : 0.f;
+                            a1 += g0;
+                            a2 += g0 * (pq[k] * q_kr + q_nb);
+                        } else {
+                            const int p = mt * 32 + rq + 8 * k;
+                            const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float pv = pq[k][e];
+                                const float g = pv > 0.f ? v[e] : 0.f;
+                                float xh = (pv * br.keep - q_beta[e]) * q_rg[e];
+                                if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
+                                    const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
+                                    xh = 0.f;                 // (no stored conv output: the block's own apply pass supplies this dgamma)
+                                    if (br.ybelow) {
+                                        const float yv = br.ybelow[(((size_t)b * br.Ty + (size_t)(t0 + tl) * br.pt) * br.Fy + (size_t)f * br.pf) * Cout + cc];
+                                        xh = (yv - br.mean[cc]) * br.rstd[cc];
+                                    }
                                 }
+                                a1[e] += g;
+                                a2[e] += g * xh;
                             }
-                            a1[e] += g;
-                            a2[e] += g * xh;
                         }
                     }
                 }
@@ -616,6 +651,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     if (stat) {
         float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
         if (BNR) {
+            a1 *= br.inv_keep;
+            a2 *= br.inv_keep;
             // lanes with equal c4 (8 row groups) hold partial sums of the same four channels
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -627,6 +664,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
             }
         } else {
+            s1 += s1v[0] + s1v[1];
+            s2 += s2v[0] + s2v[1];
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (h == 0) { red[(wave * 2 + 0) * 32 + r] = s1; red[(wave * 2 + 1) * 32 + r] = s2; }
@@ -930,6 +969,10 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
             sed_set_error("conv3x3_fwd: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernels", (size_t)B * T * F * Cin);
             return -1;
         }
+        if ((size_t)T * F * Cout >= ((size_t)1 << 30)) {
+            sed_set_error("conv3x3_fwd: one sequence's output of %zu elements exceeds the 32-bit row offsets of the MFMA kernels", (size_t)T * F * Cout);
+            return -1;
+        }
         if (mode == 1) {                     // explicit opt-in: 3-term bf16-split MFMA (wp must come from pack_weights_ex(mode 1))
             if (p.nct == 4) {
                 SED_TRY(set_lds((conv3x3_mfma_fwd_bf16x3_k<4, 2>), p.lds));
@@ -943,13 +986,13 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
             }
         } else if (p.nct == 4) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2>), p.lds));
-            conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            conv3x3_mfma_fwd2_k<4, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, 1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2));
         } else if (p.nct == 2) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<2, 2>), p.lds));
-            conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            conv3x3_mfma_fwd2_k<2, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, 1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2));
         } else {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<1, 2>), p.lds));
-            conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft);
+            conv3x3_mfma_fwd2_k<1, 2><<<grid, 256, p.lds, s>>>(x, wp, bias, y, stat, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, 1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2));
         }
     }
     SED_LAUNCH_CHECK("conv3x3_fwd");
@@ -979,12 +1022,17 @@ extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, f
         sed_set_error("conv3x3_dgrad_bnred: input of %zu elements exceeds the 32-bit staging offsets of the MFMA kernels", (size_t)B * T * F * C);
         return -1;
     }
+    if ((size_t)T * F * Cin >= ((size_t)1 << 30)) {
+        sed_set_error("conv3x3_dgrad_bnred: one sequence's output of %zu elements exceeds the 32-bit row offsets of the MFMA kernels", (size_t)T * F * Cin);
+        return -1;
+    }
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_CONV_MFMA_DGRAD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
     ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty};
     dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
     SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
-    conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft, br);
+    conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
+                                                          1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
     SED_LAUNCH_CHECK("conv3x3_dgrad_bnred");
     return 0;
 }

@@ -6,6 +6,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+__device__ unsigned long long g_clk[2];   // block 0: shader-clock ticks (s_memtime) and 100 MHz ticks (s_memrealtime) across the loop
+
 // NT accumulator tiles per wave; per group of 4 k-steps: RA ds_read_b128 for A, RB for B (0 = operands stay in registers)
 template <int NT, int RA, int RB, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters) {
@@ -19,6 +21,7 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters) {
     for (int t = 0; t < NT; ++t) a[t] = (f32x4){1.0f + lane, 0.5f, 0.25f, 2.f};
     b[0] = b[1] = (f32x4){0.001f * lane, 0.002f, 0.003f, 0.004f};
     const float* base = lds + (lane & 31) * 36 + 4 * (lane >> 5);
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
         const float* p = base + (it & 7) * 8;
 #pragma unroll
@@ -29,6 +32,7 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* out, int iters) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[0][j], acc[t], 0, 0, 0);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
     float s = 0.f;
     for (int t = 0; t < NT; ++t) for (int j = 0; j < 16; ++j) s += acc[t][j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
@@ -80,7 +84,9 @@ void run(const char* name, int blocks) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double fl = (double)blocks * WAVES * iters * NT * 4 * 4096.0;
-    printf("%-58s %8.3f ms  %7.1f TFLOP/s\n", name, ms, fl / ms / 1e9);
+    unsigned long long clk[2] = {0, 0};
+    if (!S16) hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk));
+    printf("%-58s %8.3f ms  %7.1f TFLOP/s   shader clock %.0f MHz\n", name, ms, fl / ms / 1e9, clk[1] ? clk[0] / (clk[1] * 1e-2) : 0.0);
     hipFree(out);
 }
 
