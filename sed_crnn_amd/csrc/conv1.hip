@@ -533,8 +533,9 @@ __global__ __launch_bounds__(256) void conv1_moments_stat_k(const double* __rest
 // The conv-bias gradient sum_pos dy = sc [ sum g - N sg - sgx rs (sum y - N mu) ] and, for a channel with gamma == 0, dgamma
 // = rs ( b sum g + sum_k w_k R_k - mu sum g ) come out of the same sums in the assembling kernel.
 // (launch bounds: <= 85 VGPRs, so that TWO workgroups fit into the 184 registers per lane the weight gradient leaves a SIMD)
+#define RG_U 4   // positions per thread and round of conv1_rgrad_k (loads in flight)
 template <int CIN>
-__global__ __launch_bounds__(256, CIN == 1 ? 6 : (CIN == 2 ? 4 : 2)) void conv1_rgrad_k(
+__global__ __launch_bounds__(256, CIN == 1 ? 4 : 2) void conv1_rgrad_k(
     const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ pooled,
     const unsigned char* __restrict__ bits, float* __restrict__ partials, int B, int F, int T, int C, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -546,6 +547,7 @@ __global__ __launch_bounds__(256, CIN == 1 ? 6 : (CIN == 2 ? 4 : 2)) void conv1_
     const bool active = slot < nslots;
     const int tblocks = (T + C1_TT - 1) / C1_TT, ntiles = B * tblocks;
     const int Tp = T >> 1;
+    const float invF = 1.0f / (float)F;
     f32x4 a1 = {0, 0, 0, 0};
     f32x4 rk[9 * CIN];
 #pragma unroll
@@ -556,36 +558,67 @@ __global__ __launch_bounds__(256, CIN == 1 ? 6 : (CIN == 2 ? 4 : 2)) void conv1_
         c1_stage<CIN>(halo, x, b, t0, F, T);
         __syncthreads();
         if (!active) continue;
-        for (int op = slot; op < (C1_TT / 2) * F; op += nslots) {
-            const int tpl = op / F, f = op - tpl * F;
-            const int tp = (t0 >> 1) + tpl;
-            if (tp >= Tp) break;
-            const size_t oi = ((((size_t)b * Tp + tp) * F + f) * C4 + cg) * 4;
-            const f32x4 g = *(const f32x4*)(dout + oi), pv = *(const f32x4*)(pooled + oi);
-            const unsigned bt = bits[oi >> 2];
-            f32x4 g0, g1;
+        // This pass runs beside the MFMA weight gradient of the block above, whose fp32 MFMAs leave the VALU about one issue
+        // slot per 64 cycles: its duration there is its vector-instruction count, so the loop is written for few instructions —
+        // every global address is (tile base, wave-uniform) + op * C + 4 cg, the halo row pointer needs the one division
+        // (sed_fdiv), and each tap is two fused multiply-adds per channel pair.
+        const int tp0 = t0 >> 1;
+        const int npos = ((Tp - tp0 < C1_TT / 2) ? Tp - tp0 : C1_TT / 2) * F;
+        const size_t tbase = (((size_t)b * Tp + tp0) * F) * C;
+        const char* const gb = (const char*)(dout + tbase);
+        const char* const qb = (const char*)(pooled + tbase);
+        const unsigned char* const bb = bits + (tbase >> 2);
+        // RG_U positions per round with all their loads issued first: beside the weight gradient one workgroup (4 waves) fits a
+        // CU, so the ~2-4 us of a loaded HBM round trip is hidden by loads in flight, not by other waves
+        for (int op0 = slot; op0 < npos; op0 += RG_U * nslots) {
+            f32x4 g[RG_U], pv[RG_U];
+            unsigned bt[RG_U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gv = pv[k] > 0.f ? g[k] * inv_keep : 0.f;
-                const bool second = (bt >> k) & 1u;
-                g0[k] = second ? 0.f : gv;
-                g1[k] = second ? gv : 0.f;
-                a1[k] += gv;
+            for (int u = 0; u < RG_U; ++u) {
+                const int op = op0 + u * nslots;
+                const unsigned o4 = (unsigned)((op < npos ? op : npos - 1) * C4 + cg);     // clamped: a valid address either way
+                g[u] = *(const f32x4*)(gb + o4 * 16u);
+                pv[u] = *(const f32x4*)(qb + o4 * 16u);
+                bt[u] = bb[o4];
             }
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                float hv[4][CIN];                              // the four halo rows under the window's two conv rows
+            for (int u = 0; u < RG_U; ++u) {
+                const int op = op0 + u * nslots;
+                const bool live = op < npos;
+                const int opc = live ? op : npos - 1;
+                const int tpl = sed_fdiv(opc, invF), f = opc - tpl * F;
+                f32x4 g0, g1;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
+                for (int k = 0; k < 4; ++k) {
+                    const float gv = (live && pv[u][k] > 0.f) ? g[u][k] : 0.f;     // the 1 / (1-p) is applied to the partial sums below
+                    const bool second = (bt[u] >> k) & 1u;
+                    g0[k] = second ? 0.f : gv;
+                    g1[k] = second ? gv : 0.f;
+                }
+                a1 += g0 + g1;
+                const float* hp = halo + ((tpl * 2) * F2 + f) * CIN;
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) hv[rr][ci] = halo[((tpl * 2 + rr) * F2 + f + kh) * CIN + ci];
+                for (int kh = 0; kh < 3; ++kh) {
+                    float hv[4][CIN];                              // the four halo rows under the window's two conv rows
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                    for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) rk[(kh * 3 + kw) * CIN + ci] += hv[kw][ci] * g0 + hv[kw + 1][ci] * g1;
+                        for (int ci = 0; ci < CIN; ++ci) hv[rr][ci] = hp[(rr * F2 + kh) * CIN + ci];
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int ci = 0; ci < CIN; ++ci) {
+                            f32x4& acc = rk[(kh * 3 + kw) * CIN + ci];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(hv[kw + 1][ci], g1[k], __builtin_fmaf(hv[kw][ci], g0[k], acc[k]));
+                        }
+                }
             }
         }
     }
+    a1 *= inv_keep;
+#pragma unroll
+    for (int k = 0; k < 9 * CIN; ++k) rk[k] *= inv_keep;
     // block reduction in fixed slot order, ONE value per round through a 4 KB buffer: this pass runs beside the MFMA weight
     // gradient, which leaves a CU 28 KB of LDS — with the 20 KB buffer of conv1_fused_k only one workgroup fits there (an eighth
     // of the stand-alone occupancy: that, not issue contention, is why passes crawl beside that kernel)
