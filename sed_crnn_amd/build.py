@@ -21,7 +21,10 @@ EXTRA_FLAGS = {"logmel.hip": ["-fno-slp-vectorize"],
 # Kernels whose inline-asm loads are consumed after HAND-COUNTED s_waitcnt vmcnt(N) immediates (conv.hip: the fp32 and the
 # bf16x3 conv forward).  The counts are only right while hipcc keeps the load destinations in registers between the asm load
 # and its use: a spill (scratch store/reload) would insert memory operations the counts do not know about and the MFMAs
-# could read stale fragments without any test necessarily noticing.  The build therefore FAILS if one of them spills.
+# could read stale fragments without any test necessarily noticing.  The build therefore FAILS if one of them spills — or uses
+# AGPRs at all: under register pressure hipcc parks VGPR values in AGPRs with v_accvgpr_write right after the instruction
+# that defined them, which for an asm load is BEFORE its data arrives (stale copy; the returning load then overwrites a
+# register that has been given to something else — seen as a GPU memory fault in a round-3 experiment kernel).
 NO_SPILL_KERNELS = {"conv.hip": ("conv3x3_mfma_fwd2_k", "conv3x3_mfma_fwd_bf16x3_k")}
 
 
@@ -52,7 +55,7 @@ def check_no_spill(remarks, kernels):
                 seen.add(cur)
             continue
         if cur:
-            m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", line)
+            m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|AGPRs): (\d+)", line)
             if m and int(m.group(2)) != 0 and not m.group(1).startswith("SGPRs"):
                 bad.append(f"{cur}: {m.group(1)} = {m.group(2)}")
     bad += [f"{k}: no resource-usage remark found (kernel renamed? update NO_SPILL_KERNELS)" for k in kernels if k not in seen]

@@ -385,7 +385,7 @@ def test_integration_md_stubs_match_the_binding_table():
 
 def test_build_guard_refuses_spills_in_the_hand_counted_waitcnt_kernels():
     """build.py compiles conv.hip with -Rpass-analysis=kernel-resource-usage and fails when a kernel whose vmcnt immediates are
-    counted by hand (conv3x3_mfma_fwd2_k, conv3x3_mfma_fwd_bf16x3_k) reports scratch or a VGPR spill (round-2 advisor)"""
+    counted by hand (conv3x3_mfma_fwd2_k, conv3x3_mfma_fwd_bf16x3_k) reports scratch, a VGPR spill (round-2 advisor) or any AGPR"""
     from sed_crnn_amd.build import NO_SPILL_KERNELS, check_no_spill
     ks = NO_SPILL_KERNELS["conv.hip"]
     ok = "".join(f"a.hip:1:1: remark: Function Name: _Z3{k}ILi4EE [-R]\na.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-R]\n"
@@ -393,6 +393,8 @@ def test_build_guard_refuses_spills_in_the_hand_counted_waitcnt_kernels():
     assert check_no_spill(ok, ks) == []
     assert any("VGPRs Spill = 4" in b for b in check_no_spill(ok.replace("VGPRs Spill: 0", "VGPRs Spill: 4", 1), ks))
     assert any("ScratchSize" in b for b in check_no_spill(ok.replace("lane]: 0", "lane]: 24", 1), ks))
+    with_agpr = ok.replace("a.hip:1:1: remark:     VGPRs Spill: 0 [-R]\n", "a.hip:1:1: remark:     VGPRs Spill: 0 [-R]\na.hip:1:1: remark:     AGPRs: 12 [-R]\n", 1)
+    assert any("AGPRs = 12" in b for b in check_no_spill(with_agpr, ks))          # values parked in AGPRs: asm-load destinations may move
     assert any("no resource-usage remark" in b for b in check_no_spill("", ks))        # a rename cannot disable the guard
     other = "a.hip:1:1: remark: Function Name: _Z9some_else [-R]\na.hip:1:1: remark:     VGPRs Spill: 9 [-R]\n"
     assert check_no_spill(ok + other, ks) == []
