@@ -148,6 +148,15 @@ int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const fl
                                      int pool_t, int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
                         float* dgamma, float* dbeta, void* stream);
+/* The reduce pass of the block that feeds the GRU (out_tcf layout [B][T/pt][C][F/pf]) formed from that block's own pooled
+ * OUTPUT and its gradient instead of the conv output: the same partial rows (sed_bn_bwd_rows) for sed_bn_bwd_finalize.
+ * pooled > 0 exactly where the gradient passes, and the BatchNorm output at the arg-max is pooled*(1-p), so
+ * xhat = (pooled*(1-p) - beta)/gamma; `y` (the conv output) is read only for channels with gamma == 0 and beta > 0.
+ * _supported: out_tcf, F/pool_f a multiple of 4 and C*F/pool_f <= 16384; otherwise use sed_bn_relu_pool_drop_bwd_reduce. */
+int sed_bn_bwd_reduce_pooled_supported(int F, int C, int pool_f, int pool_t, int out_tcf);
+int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, const float* gamma, const float* beta,
+                             const float* y, const float* mean, const float* rstd, float* partials,
+                             int B, int T, int F, int C, int pool_f, int pool_t, int out_tcf, float drop_p, void* stream);
 int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const float* scale,
                                     const float* shift, const float* mean, const float* rstd,
                                     const float* sum_g, const float* sum_gx, float* dy,

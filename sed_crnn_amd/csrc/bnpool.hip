@@ -479,6 +479,136 @@ extern "C" int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dou
     return 0;
 }
 
+// ── reduction pass of the block that feeds the GRU, from its own pooled output ──
+// The same identities as the BNR epilogue of the conv data gradient (conv.hip): the pooled output q = relu(max z) mask/(1-p)
+// is > 0 exactly where the gradient passes, g = dout/(1-p) there, and the BatchNorm output at the arg-max is z = q (1-p), so
+// xhat = (z - beta)/gamma.  The pass reads the pooled tensor and its gradient ([B][Tp][C][Fp], the GRU layout) instead of
+// the conv output (pt*pf times larger) and needs neither the arg-max search nor the dropout hash.  gamma == 0 (z constant):
+// beta <= 0 -> nothing passes; beta > 0 -> every window is a tie whose arg-max is its first element, xhat from the conv output.
+// Thread t owns the float4s i = t + 256 k of a row, which lie in channel i / (Fp/4) for every row: BP_K accumulator pairs per
+// thread, summed per channel in fixed order at the end (deterministic).
+#define BP_K 8           // max float4 per thread and row; the kernel is instantiated for the exact count (registers: it runs beside a GEMM)
+template <int BPK, int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_pooled_tcf_k(
+    const float* __restrict__ pooled, const float* __restrict__ dout, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ y, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ partials, int B, int T, int F, int C, int pf, int pt, float drop_p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][C * Fp / 4]
+    const int Tp = T / pt, Fp = F / pf, F4 = Fp >> 2, n4 = C * F4, tid = threadIdx.x;
+    const float keep = 1.f - drop_p, inv_keep = 1.f / keep;
+    float a1[BPK], a2[BPK], kr[BPK], nb[BPK];
+    unsigned slow = 0;                                    // bit k: gamma == 0 and beta > 0
+#pragma unroll
+    for (int k = 0; k < BPK; ++k) {
+        a1[k] = a2[k] = kr[k] = nb[k] = 0.f;
+        const int i = tid + NT * k;
+        if (i < n4) {
+            const int c = i / F4;
+            const float gm = gamma[c], bt = beta[c];
+            const float rg = gm != 0.f ? 1.0f / gm : 0.f;
+            kr[k] = keep * rg;
+            nb[k] = -bt * rg;
+            if (gm == 0.f && bt > 0.f) slow |= 1u << k;
+        }
+    }
+    const long rows = (long)B * Tp;
+    constexpr int CH = BPK < 8 ? BPK : 8;                 // float4 pairs in flight per thread (registers: this pass runs beside a GEMM)
+#pragma unroll 1
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const f32x4* q4 = (const f32x4*)(pooled + (size_t)r * C * Fp);
+        const f32x4* d4 = (const f32x4*)(dout + (size_t)r * C * Fp);
+#pragma unroll
+        for (int k0 = 0; k0 < BPK; k0 += CH) {
+            f32x4 qv[CH], dv[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = tid + NT * (k0 + k);
+                if (k0 + k < BPK && i < n4) { qv[k] = q4[i]; dv[k] = d4[i]; }
+            }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = tid + NT * (k0 + k);
+                if (k0 + k < BPK && i < n4) {
+                    f32x4 g0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g0[e] = qv[k][e] > 0.f ? dv[k][e] : 0.f;
+                    const f32x4 gx = g0 * (qv[k] * kr[k0 + k] + nb[k0 + k]);          // gamma == 0 channels: kr = nb = 0, added below
+                    a1[k0 + k] += (g0[0] + g0[1]) + (g0[2] + g0[3]);
+                    a2[k0 + k] += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (slow) {                                           // measure zero: xhat at the window's first element of the conv output
+#pragma unroll 1
+        for (int k = 0; k < BPK; ++k) {
+            if (!((slow >> k) & 1u)) continue;
+            const int i = tid + NT * k, c = i / F4, fp0 = (i - c * F4) * 4;
+            const float mu = mean[c], rs = rstd[c];
+            float s2 = 0.f;
+            for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+                const f32x4 qv = ((const f32x4*)(pooled + (size_t)r * C * Fp))[i], dv = ((const f32x4*)(dout + (size_t)r * C * Fp))[i];
+                const long b = r / Tp, tp = r - b * Tp;
+                for (int e = 0; e < 4; ++e) {
+                    const float yv = y[(((size_t)b * T + (size_t)tp * pt) * F + (size_t)(fp0 + e) * pf) * C + c];
+                    if (qv[e] > 0.f) s2 += dv[e] * ((yv - mu) * rs);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < BPK; ++kk) if (kk == k) a2[kk] += s2;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BPK; ++k) {
+        const int i = tid + NT * k;
+        if (i < n4) { smem[i] = a1[k] * inv_keep; smem[n4 + i] = a2[k] * inv_keep; }
+    }
+    __syncthreads();
+    for (int j = tid; j < 2 * C; j += NT) {
+        const int which = j / C, c = j - which * C;
+        float a = 0.f;
+        for (int f = 0; f < F4; ++f) a += smem[which * n4 + c * F4 + f];
+        partials[(size_t)blockIdx.x * 2 * C + j] = a;
+    }
+}
+
+extern "C" int sed_bn_bwd_reduce_pooled_supported(int F, int C, int pool_f, int pool_t, int out_tcf) {
+    if (!out_tcf || F <= 0 || C <= 0 || pool_f <= 0 || pool_t <= 0 || F % pool_f != 0) return 0;
+    const int Fp = F / pool_f;
+    return (Fp % 4 == 0 && (long)C * (Fp / 4) <= 1024L * 4) ? 1 : 0;       // 256 threads x <= 8 float4, or 1024 x <= 4
+}
+
+extern "C" int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, const float* gamma, const float* beta,
+                                        const float* y, const float* mean, const float* rstd, float* partials,
+                                        int B, int T, int F, int C, int pf, int pt, int out_tcf, float drop_p, void* stream) {
+    SED_REQUIRE(pooled && dout && gamma && beta && y && mean && rstd && partials, "bn_bwd_reduce_pooled: null pointer");
+    SED_TRY(check_pool("bn_bwd_reduce_pooled", B, T, F, C, pf, pt));
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_bwd_reduce_pooled: bad drop_p");
+    SED_REQUIRE(sed_bn_bwd_reduce_pooled_supported(F, C, pf, pt, out_tcf),
+                "bn_bwd_reduce_pooled: needs the GRU layout, F/pool_f a multiple of 4 and C*F/pool_f <= 16384 (use sed_bn_relu_pool_drop_bwd_reduce)");
+    const int grid = sed_bn_bwd_rows(B, T, pt);
+    const size_t lds = (size_t)2 * C * (F / pf / 4) * sizeof(float);
+    SedProfScope prof(SED_K_BN_BWD_REDUCE, as_stream(stream), 8.0 * B * C * (double)(T / pt) * (F / pf));
+    const long n4 = (long)C * (F / pf / 4);
+    const int nt = n4 <= 256L * BP_K ? 256 : 1024, need = cdiv(n4, nt);
+#define BP_LAUNCH(K_, NT_) bn_bwd_reduce_pooled_tcf_k<K_, NT_><<<grid, NT_, lds, as_stream(stream)>>>(pooled, dout, gamma, beta, y, mean, rstd, partials, B, T, F, C, pf, pt, drop_p)
+    if (nt == 256) {
+        switch (need) {
+            case 1: BP_LAUNCH(1, 256); break;   case 2: BP_LAUNCH(2, 256); break;   case 3: BP_LAUNCH(3, 256); break;
+            case 4: BP_LAUNCH(4, 256); break;   case 5: BP_LAUNCH(5, 256); break;   case 6: BP_LAUNCH(6, 256); break;
+            case 7: BP_LAUNCH(7, 256); break;   default: BP_LAUNCH(8, 256); break;
+        }
+    } else {
+        switch (need) {                     // 9..16 float4 per thread at 256 threads: 3..4 at 1024
+            case 3: BP_LAUNCH(3, 1024); break;   default: BP_LAUNCH(4, 1024); break;
+        }
+    }
+#undef BP_LAUNCH
+    SED_LAUNCH_CHECK("bn_bwd_reduce_pooled");
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, float* sum_g,
                                                          float* sum_gx, float* dgamma, float* dbeta) {
     __shared__ double s1[32][9], s2[32][9];

@@ -369,6 +369,10 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
             SED_TRY(sed_conv1_bwd_reduce(x, ws + L.wp_f[l], p->conv_b[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                          ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.Cin, q.F, q.T, q.C, q.pf, q.pt,
                                          q.drop, sd, seed_dev, st));
+        else if (sed_bn_bwd_reduce_pooled_supported(q.F, q.C, q.pf, q.pt, last))
+            // the block that feeds the GRU: the sums from its pooled output and that tensor's gradient (1/pt of the conv output)
+            SED_TRY(sed_bn_bwd_reduce_pooled(ws + L.pooled[l], ws + L.gradA, p->bn_g[l], p->bn_b[l], ws + L.conv_out[l],
+                                             ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, st));
         else
             SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                                      ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf,

@@ -102,6 +102,22 @@ def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out
     return dy, dgamma, dbeta, dbias
 
 
+def bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, y, mean, rstd, pool_f, pool_t, drop_p=0.0):
+    """(sum g, sum g*xhat) of the GRU-feeding block from its pooled output [B,Tp,C,Fp] and that tensor's gradient
+    (sed_bn_bwd_reduce_pooled + sed_bn_bwd_finalize); y [B,T,F,C] is read for gamma == 0 channels only"""
+    B, T, F, Cc = y.shape
+    if not lib().sed_bn_bwd_reduce_pooled_supported(F, Cc, pool_f, pool_t, 1):
+        raise ValueError("bn_bwd_sums_from_pooled: shape not supported")
+    rows = lib().sed_bn_bwd_rows(B, T, pool_t)
+    part = torch.empty(rows, 2, Cc, device=y.device)
+    check(lib().sed_bn_bwd_reduce_pooled(ptr(_f32c(pooled)), ptr(_f32c(dout)), ptr(gamma), ptr(beta), ptr(_f32c(y)), ptr(mean),
+                                         ptr(rstd), ptr(part), B, T, F, Cc, pool_f, pool_t, 1, drop_p, stream_ptr()),
+          "bn_bwd_reduce_pooled")
+    sum_g, sum_gx = torch.empty(Cc, device=y.device), torch.empty(Cc, device=y.device)
+    check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), None, None, stream_ptr()), "bn_bwd_finalize")
+    return sum_g, sum_gx
+
+
 def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0):
     """data gradient of a conv block + the BatchNorm-backward sums of the block below in its epilogue
     -> (dx [B,T,F,Cin], sum_g [Cin], sum_gx [Cin]); dy [B,T,F,C], wd = the dgrad packing [9,Cin,C]"""

@@ -270,6 +270,36 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
     assert float(sum_gx[3].abs()) > 0.0
 
 
+@pytest.mark.parametrize("B,Ty,Fy,C,pf,pt,p", [(3, 16, 40, 128, 1, 2, 0.5), (2, 12, 40, 128, 1, 2, 0.0), (2, 9, 40, 128, 1, 2, 0.5),
+                                                (1, 8, 128, 128, 1, 2, 0.5), (2, 6, 48, 64, 3, 1, 0.25), (5, 4, 16, 32, 2, 2, 0.3)])
+def test_bn_backward_sums_of_the_gru_feeding_block_from_its_pooled_output(ops, B, Ty, Fy, C, pf, pt, p):
+    """sed_bn_bwd_reduce_pooled: (sum g, sum g*xhat) of the block that feeds the GRU, formed from its pooled output
+    [B,Tp,C,Fp] and that tensor's gradient, against the pass that re-reads the conv output, finds the arg-max and regenerates
+    the dropout mask (sed_bn_relu_pool_drop_bwd_reduce): to rounding.  gamma == 0 channels of both beta signs, a negative
+    gamma, ragged time tails, mel pooling and config 5's 128 mel bins are in."""
+    gen = torch.Generator().manual_seed(B * 100 + Ty + Fy + C)
+    yb = torch.randn(B, Ty, Fy, C, generator=gen).cuda()
+    gamma = (torch.rand(C, generator=gen) + 0.5)
+    beta = torch.randn(C, generator=gen) * 0.3
+    gamma[3], beta[3] = 0.0, 0.5
+    gamma[17], beta[17] = 0.0, -0.2
+    gamma[20] = -0.7
+    gamma, beta = gamma.cuda(), beta.cuda()
+    flat = yb.reshape(-1, C)
+    part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).reshape(1, 2, C).contiguous()
+    mean, rstd, scale, shift = ops.bn_finalize_train(part, B * Ty * Fy, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda())
+    seed = 7
+    pooled = ops.bn_relu_pool_drop_fwd(yb, scale, shift, pf, pt, out_tcf=True, drop_p=p, seed=seed)       # [B,Tp,C,Fp]
+    dout = (torch.randn(pooled.shape, generator=gen) * 0.1).cuda()
+    _, dgamma_ref, dbeta_ref, _ = ops.bn_relu_pool_drop_bwd(yb, dout, scale, shift, mean, rstd, pf, pt, out_tcf=True, drop_p=p, seed=seed)
+    sum_g, sum_gx = ops.bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p)
+    mag = float((dout.abs() / (1.0 - p)).sum(dim=(0, 1, 3)).max())
+    close(sum_g, dbeta_ref, atol=2e-6 * mag, rtol=1e-4)
+    close(sum_gx, dgamma_ref, atol=6e-6 * mag, rtol=1e-4)
+    assert float(sum_g[17].abs()) == 0.0 and float(sum_gx[17].abs()) == 0.0
+    assert float(sum_gx[3].abs()) > 0.0
+
+
 def test_bn_eval_scale_shift(ops):
     Cc = 16
     gen = torch.Generator().manual_seed(5)
