@@ -45,6 +45,11 @@ struct SedProfScope {
     ~SedProfScope() { if (on) sed_prof_end(tag, s); }
 };
 
+// internal (conv.hip): the fp32 weight packing of up to SED_MAX_CONV layers in ONE launch (the forward packs every conv layer
+// of a step up front instead of once per layer on the critical chain); same layouts as sed_conv3x3_pack_weights
+int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
+                                 void* stream);
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -133,6 +133,33 @@ extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, in
     return 0;
 }
 
+struct ConvPackMulti { const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int Cout[SED_MAX_CONV], Cin[SED_MAX_CONV]; };
+__global__ void conv_pack_w_multi_k(ConvPackMulti a) {
+    const int l = blockIdx.y, Cout = a.Cout[l], Cin = a.Cin[l];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * Cin * 9) return;
+    const int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+    const float v = a.w[l][i];
+    const bool frag = (Cin % 32 == 0) && (Cout % 32 == 0);
+    if (a.wf[l]) a.wf[l][frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
+    if (a.wd[l]) a.wd[l][frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+}
+int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
+                                 void* stream) {
+    SED_REQUIRE(n > 0 && n <= SED_MAX_CONV && w && wf && wd && Cout && Cin, "conv_pack_multi: bad arguments");
+    ConvPackMulti a{};
+    int nmax = 0;
+    for (int l = 0; l < n; ++l) {
+        SED_REQUIRE(w[l] && Cout[l] > 0 && Cin[l] > 0, "conv_pack_multi: bad layer %d", l);
+        a.w[l] = w[l]; a.wf[l] = wf[l]; a.wd[l] = wd[l]; a.Cout[l] = Cout[l]; a.Cin[l] = Cin[l];
+        const int nl = Cout[l] * Cin[l] * 9;
+        if (nl > nmax) nmax = nl;
+    }
+    conv_pack_w_multi_k<<<dim3(cdiv(nmax, 256), n), 256, 0, as_stream(stream)>>>(a);
+    SED_LAUNCH_CHECK("conv_pack_w_multi");
+    return 0;
+}
+
 // ── 3-term bf16-split path (EXPERIMENT, explicit opt-in: mode 1 of the *_ex entries; never the default) ──
 // w = hi + lo with hi = bf16(w), lo = bf16(w - hi); a*b ~ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16
 // (fp32 accumulate): three bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles, i.e. 5.3x the matrix

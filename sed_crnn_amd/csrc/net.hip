@@ -206,6 +206,18 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
     SED_REQUIRE(pb >= 0 && pe <= 2 * L.n_conv + 1 && pb < pe, "net_forward: bad phase range [%d,%d)", pb, pe);
     float* ws = (float*)workspace;
     const int B = c->B;
+    // a call that starts at phase 0 packs the weights of EVERY conv layer in one launch (exact-fp32 layouts), instead of one
+    // 5 us launch per layer standing between the layers of the critical chain
+    const bool packed_up_front = pb == 0 && c->conv_mode == 0 && L.n_conv > 1;
+    if (packed_up_front) {
+        const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int co[SED_MAX_CONV], ci[SED_MAX_CONV];
+        for (int l = 0; l < L.n_conv; ++l) {
+            SED_REQUIRE(p->conv_w[l], "net_forward: missing parameters of conv block %d", l);
+            w[l] = p->conv_w[l]; wf[l] = ws + L.wp_f[l]; wd[l] = (training && l > 0) ? ws + L.wp_d[l] : nullptr;
+            co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin;
+        }
+        SED_TRY(sed_internal_conv_pack_multi(L.n_conv, w, wf, wd, co, ci, stream));
+    }
     for (int l = 0; l < L.n_conv; ++l) {
         const ConvL& q = L.cv[l];
         const float* in = (l == 0) ? x : ws + L.pooled[l - 1];
@@ -215,8 +227,9 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
                     "net_forward: missing parameters of conv block %d", l);
         if (do_a) {
-            SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
-                                                q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
+            if (!packed_up_front)
+                SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
+                                                    q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
             if (q.fused) {
                 if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C,
                                                       q.rgrad ? (double*)(ws + L.c1_mom) : nullptr, stream));
