@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256, CIN == 1 ? 4 : 2) void conv1_rgrad_k(
             int j = i / C, c = i - j * C;
             float a = 0.f;
             for (int s2 = 0; s2 < nslots; ++s2) a += red[(s2 * NVC + j) * C + c];
-            partials[(size_t)blockIdx.x * NV * C + (size_t)(v0 + j) * C + c] = a;
+            partials[((size_t)blockIdx.x * C + c) * NV + (v0 + j)] = a;      // [workgroup][channel][value]: the assembling kernel reads a channel's NV values as one run
         }
     }
 }
@@ -658,12 +658,23 @@ __global__ __launch_bounds__(256) void conv1_wgrad_assemble_k(
     __shared__ double sv[37];                                 // [0] sum g, [1..NK] R_k
     __shared__ double sw[4][37];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int v = 0; v < NV; ++v) {                            // 256 row slices, 8 independent loads in flight per thread
-        double a = 0.0;
-#pragma unroll 8
-        for (int r = threadIdx.x; r < rows; r += 256) a += (double)part[((size_t)r * NV + v) * C + co];
-        a = wave_sum_d(a);
-        if (lane == 0) sw[wv][v] = a;
+    {   // a thread sums whole rows: the NV values of (workgroup r, channel co) are one 40..148-byte run
+        double a[37];
+#pragma unroll
+        for (int v = 0; v < 37; ++v) a[v] = 0.0;
+        for (int r = threadIdx.x; r < rows; r += 256) {
+            const float* pr = part + ((size_t)r * C + co) * NV;
+#pragma unroll
+            for (int v = 0; v < 37; ++v)
+                if (v < NV) a[v] += (double)pr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < 37; ++v) {
+            if (v < NV) {
+                const double t = wave_sum_d(a[v]);
+                if (lane == 0) sw[wv][v] = t;
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < NV) sv[threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
