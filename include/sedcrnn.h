@@ -102,6 +102,16 @@ int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, f
                             const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                             const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                             int B, int C, int F, int T, int Cin, void* stream);
+/* The same launch when the block below is the recomputed 1-channel first block with pool (1,2) (sed.py:86-92, ch = 1): the
+ * epilogue also forms that block's weight-gradient sums — rg_partials [rows][Cin][10] = (sum g, R_0..R_8) per channel and
+ * workgroup, R_{3kh+kw} = sum g~ x[f+kh-1][2t'+sel+kw-1] with sel the arg-max bit — from the network input x1 [B][1][F][2T] and
+ * the arg-max bits of sed_conv1_bn_relu_pool_drop_fwd, for sed_conv1_bwd_wgrad_assemble.  Replaces the pass of
+ * sed_conv1_bwd_wgrad over dx, the pooled tensor and the bits.  rows = sed_conv3x3_dgrad_bnred_rg_rows(); 0 = not supported. */
+int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin);
+int sed_conv3x3_dgrad_bnred_rg(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                               const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
+                               const float* x1, const unsigned char* argmax_bits, float* rg_partials,
+                               int B, int C, int F, int T, int Cin, void* stream);
 
 /* ───────────── BatchNorm2d + ReLU + MaxPool2d + Dropout (sed.py:89-92,107; crnn_lightning.py:48-52) ─────────────
  * Training statistics: reduce the conv partials in a fixed order (double accumulation),
@@ -219,6 +229,11 @@ int sed_conv1_bwd_wgrad(const float* x, const float* dout, const float* pooled, 
                         const float* scale, const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                         void* workspace, int B, int Cin, int F, int T, int C, float drop_p,
                         const float* gamma, const float* beta, float* dgamma, void* stream);
+/* its assembling half alone, from partials [rows][C][1 + 9 Cin] formed elsewhere (sed_conv3x3_dgrad_bnred_rg) */
+int sed_conv1_bwd_wgrad_assemble(const float* partials, int rows, const double* moments, const float* wp, const float* bias,
+                                 const float* mean, const float* rstd, const float* scale, const float* sum_g,
+                                 const float* sum_gx, float* dw_oihw, float* dbias, int B, int Cin, int F, int T, int C,
+                                 const float* gamma, const float* beta, float* dgamma, void* stream);
 
 /* ───────────── dense GEMM on fp32 MFMA (aten::mm/addmm under nn.GRU / nn.Linear, sed.py:101-103) ─────────────
  * C[i][j] = sum_k A(i,k) * B(k,j) (+ bias[j]) (+ beta*C[i][j]), C row-major with leading dim ldc.

@@ -384,9 +384,14 @@ struct ConvBnRed {
     const float* rstd;
     float keep, inv_keep;    // 1 - p, 1 / (1 - p)
     int pf, pt, Fy, Ty;      // pool and the extents of ybelow
+    // RG (the block below is the recomputed 1-channel first block, pool (1,2)): also its weight-gradient sums, see the kernel
+    const float* x1;         // the network input [B][1][Fy][Ty]
+    const unsigned char* bits;   // arg-max bits of the block below: [B][T][F][Cout/4] bytes, bit e = channel 4q+e took the second time row
+    float* rgp;              // out: [rows][Cout][10] = (sum g, R_0..R_8) per workgroup
+    float invXT;             // 1 / (2 TT + 2)
 };
 
-template <int NCT, int MINW, bool BNR = false>
+template <int NCT, int MINW, bool BNR = false, bool RG = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft,
@@ -445,11 +450,24 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // epilogue's duration IS its VALU instruction count x 64 cycles (measured with s_memrealtime stamps: 850 VALU instructions,
     // 22 us per workgroup, against 3.4 us with the CU to itself) — address arithmetic was half of them.
     unsigned* rowtab = (unsigned*)(smem + (2 * HB > 4 * 1024 + 256 ? 2 * HB : 4 * 1024 + 256));
+    // RG: a second table (the position of a row's 3 x 4 input window in xs) and xs itself, the (FT + 2) x (2 TT + 2) patch of
+    // the 1-channel network input under this tile's pooled rows (time fastest, zero outside the input)
+    unsigned* xofftab = rowtab + 32 * CV_MTW * MPARTS;
+    float* xs = (float*)(xofftab + 32 * CV_MTW * MPARTS);
+    const int XT = 2 * TT + 2;
     for (int sidx = tid; sidx < nMT * 32; sidx += 256) {
         const int p = (sidx & ~31) + ((sidx >> 2) & 7) + 8 * (sidx & 3);
         const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
         const bool ok = p < MROWS && t0 + tl < T && f < F;
         rowtab[sidx] = ok ? (unsigned)(((t0 + tl) * F + f) * Cout) * 4u : 0xFFFFFFFFu;
+        if (RG) xofftab[sidx] = (unsigned)((p - tl * FT) * XT + 2 * tl);
+    }
+    if (RG) {
+        for (int i = tid; i < F2 * XT; i += 256) {
+            const int ff = sed_fdiv(i, br.invXT), tt = i - ff * XT;
+            const int f = f0 + ff - 1, t = 2 * t0 + tt - 1;
+            xs[i] = (f >= 0 && f < F && t >= 0 && t < br.Ty) ? br.x1[((size_t)b * F + f) * br.Ty + t] : 0.f;
+        }
     }
 
     // Halo staging.  Every lane issues all CV_NH loads of a chunk from a clamped (always valid) address and zeroes the
@@ -592,6 +610,13 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     }
     const bool anyslow = BNR && __builtin_amdgcn_ballot_w64(slowmask != 0) != 0;     // wave-uniform, measure zero
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // RG: the first block's weight-gradient sums R[kh*3+kw] = sum g~ x[f+kh-1][2t'+sel+kw-1] (sel = the arg-max bit), which
+    // conv1_rgrad_k otherwise forms in a pass of its own over dx (this kernel's output), the pooled tensor and the bits: 750 MB
+    // that trailed the last weight gradient by 0.13 ms.  Here dx and the pooled values are in registers already.
+    f32x4 R[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = (f32x4){0, 0, 0, 0};
+    const unsigned char* const bq = RG ? br.bits + (size_t)b * T * F * (Cout >> 2) + ((co0 + ct * 32 + c4) >> 2) : nullptr;
     auto store_tiles = [&](auto checked) {
         constexpr bool CHK = decltype(checked)::value;
 #pragma unroll
@@ -600,6 +625,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             if (mt < nMT) {
                 const u32x4 rr = *(const u32x4*)(rowtab + mt * 32 + rq * 4);              // rows rq + 8 k of this tile
                 const u32x4 ro = rr + (unsigned)(c4 * 4);
+                u32x4 xo = {0, 0, 0, 0};
+                unsigned bt[4] = {0, 0, 0, 0};
+                if (RG) {
+                    xo = *(const u32x4*)(xofftab + mt * 32 + rq * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!CHK || rr[k] != 0xFFFFFFFFu) bt[k] = bq[rr[k] >> 4];
+                }
                 // BNR: this tile's pooled values, requested before the transpose so that they arrive under it
                 f32x4 pq[4];
                 if (BNR) {
@@ -639,11 +672,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                     const bool ok = !CHK || rr[k] != 0xFFFFFFFFu;
                     if (ok) *(f32x4*)(yb + ro[k]) = v;
                     if (BNR && ok) {
-                        if (!anyslow) {
-                            // g = v / (1-p) where the pooled value is > 0; the 1 / (1-p) is applied to the sums at the end
-                            f32x4 g0;
+                        // g = v / (1-p) where the pooled value is > 0; the 1 / (1-p) is applied to the sums at the end
+                        f32x4 g0;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) g0[e] = pq[k][e] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) g0[e] = pq[k][e] > 0.f ? v[e] : 0.f;
+                        if (!anyslow) {
                             a1 += g0;
                             a2 += g0 * (pq[k] * q_kr + q_nb);
                         } else {
@@ -652,7 +685,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float pv = pq[k][e];
-                                const float g = pv > 0.f ? v[e] : 0.f;
                                 float xh = (pv * br.keep - q_beta[e]) * q_rg[e];
                                 if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
                                     const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
@@ -662,8 +694,22 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                                         xh = (yv - br.mean[cc]) * br.rstd[cc];
                                     }
                                 }
-                                a1[e] += g;
-                                a2[e] += g * xh;
+                                a1[e] += g0[e];
+                                a2[e] += g0[e] * xh;
+                            }
+                        }
+                        if (RG) {
+                            f32x4 g1;                         // the share of the window's second time row
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g1[e] = ((bt[k] >> e) & 1u) ? g0[e] : 0.f;
+                            const f32x4 gA = g0 - g1;
+                            const float* xb = xs + xo[k];
+#pragma unroll
+                            for (int kh = 0; kh < 3; ++kh) {
+                                const f32x2 x01 = *(const f32x2*)(xb + kh * XT), x23 = *(const f32x2*)(xb + kh * XT + 2);
+                                R[kh * 3 + 0] += gA * x01[0] + g1 * x01[1];
+                                R[kh * 3 + 1] += gA * x01[1] + g1 * x23[0];
+                                R[kh * 3 + 2] += gA * x23[0] + g1 * x23[1];
                             }
                         }
                     }
@@ -690,6 +736,19 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
                 *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
             }
+            if (RG) {                                 // [4 waves][9][32] behind `red`: this wave's 32 channels of R_0..R_8
+                float* red2 = smem + 4 * 1024 + 256;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    R[k] *= br.inv_keep;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                        for (int o = 8; o < 64; o <<= 1) R[k][e] += __shfl_xor(R[k][e], o, 64);
+                    }
+                    if (lane < 8) *(f32x4*)(red2 + (wave * 9 + k) * 32 + c4) = R[k];
+                }
+            }
         } else {
             s1 += s1v[0] + s1v[1];
             s2 += s2v[0] + s2v[1];
@@ -706,6 +765,14 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
             for (int m = 0; m < MPARTS; ++m) a += red[((m * NCT + cti) * 2 + which) * 32 + cr];
             stat[row * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+        if (RG && tid < WROWS) {                      // MPARTS == 1: wave ct owns channels 32 ct .. 32 ct + 31
+            const int cti = tid >> 5, cr = tid & 31;
+            float* o = br.rgp + (row * Cout + co0 + tid) * 10;
+            o[0] = red[(cti * 2 + 0) * 32 + cr];      // sum g (= the BatchNorm sum above)
+            const float* red2 = smem + 4 * 1024 + 256;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) o[1 + k] = red2[(cti * 9 + k) * 32 + cr];
         }
     }
 }
@@ -955,6 +1022,11 @@ static int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+// LDS of the data gradient with the first block's weight-gradient sums: + the window-offset table + the input patch
+static size_t dgrad_rg_lds(const ConvPlan& p) {
+    return p.lds + (size_t)32 * CV_MTW * sizeof(unsigned) + ((size_t)(2 * p.TT + 2) * (p.FT + 2) + 4) * sizeof(float);
+}
+
 extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
                                float* stat, int B, int Cin, int F, int T, int Cout, void* stream) {
     return sed_conv3x3_fwd_ex(x, x_is_nchw, wp, bias, y, stat, B, Cin, F, T, Cout, 0, stream);
@@ -1035,14 +1107,15 @@ extern "C" int sed_conv3x3_dgrad_bnred_rows(int B, int C, int F, int T, int Cin)
     return (p.kind == 1 && p.nct == 4) ? p.rows : 0;
 }
 
-extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
-                                       const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
-                                       const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
-                                       int B, int C, int F, int T, int Cin, void* stream) {
+static int dgrad_bnred_impl(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                            const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                            const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                            const float* x1, const unsigned char* bits, float* rg_partials,
+                            int B, int C, int F, int T, int Cin, void* stream) {
     SED_REQUIRE(dy && wp_dgrad && dx && partials && pooled && gamma && beta && mean && rstd, "conv3x3_dgrad_bnred: null pointer");
     SED_REQUIRE(B > 0 && C > 0 && F > 0 && T > 0 && Cin > 0, "conv3x3_dgrad_bnred: bad shape B=%d C=%d F=%d T=%d Cin=%d", B, C, F, T, Cin);
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f && pool_f >= 1 && pool_t >= 1, "conv3x3_dgrad_bnred: bad drop_p / pool");
-    SED_REQUIRE(Ty / pool_t == T && Fy / pool_f == F, "conv3x3_dgrad_bnred: conv output %dx%d does not pool (%d,%d) to %dx%d", Ty, Fy, pool_t, pool_f, T, F);
+    SED_REQUIRE(Ty / pool_t == T && Fy / pool_f == F, "conv3x3_dgrad_bnred: conv output %dx%d does not pool (%d,%d) to %dx%d", Ty, Fy, pool_f, pool_t, T, F);
     ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
     SED_REQUIRE(p.kind == 1 && p.nct == 4, "conv3x3_dgrad_bnred: C=%d -> Cin=%d does not take the 128-wide MFMA path", C, Cin);
     if ((size_t)B * T * F * C >= ((size_t)1 << 32)) {
@@ -1055,13 +1128,48 @@ extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, f
     }
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_CONV_MFMA_DGRAD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
-    ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty};
+    ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty,
+                 x1, bits, rg_partials, 1.0f / (float)(2 * p.TT + 2)};
     dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
-    SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
-    conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
-                                                          1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+    if (x1) {
+        const size_t lds = dgrad_rg_lds(p);
+        SED_REQUIRE(bits && rg_partials && pool_f == 1 && pool_t == 2 && Ty == 2 * T && lds <= 80 * 1024,
+                    "conv3x3_dgrad_bnred_rg: needs pool (1,2), an even conv time extent and a tile that leaves two workgroups per CU");
+        SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true, true>), lds));
+        conv3x3_mfma_fwd2_k<4, 2, true, true><<<grid, 256, lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
+                                                                    1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+    } else {
+        SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
+        conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
+                                                              1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+    }
     SED_LAUNCH_CHECK("conv3x3_dgrad_bnred");
     return 0;
+}
+
+extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                                       const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                                       const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                                       int B, int C, int F, int T, int Cin, void* stream) {
+    return dgrad_bnred_impl(dy, wp_dgrad, dx, partials, pooled, gamma, beta, conv_out_below, mean, rstd, drop_p, pool_f, pool_t, Fy, Ty,
+                            nullptr, nullptr, nullptr, B, C, F, T, Cin, stream);
+}
+
+// The same launch when the block below is the recomputed 1-channel first block with pool (1,2): the epilogue also forms that
+// block's weight-gradient sums (sum g, R_0..R_8 per channel and workgroup -> rg_partials [rows][Cin][10], rows =
+// sed_conv3x3_dgrad_bnred_rg_rows) from the network input x1 [B][1][F][2T] and the arg-max bits of its forward, for
+// sed_conv1_bwd_wgrad_assemble.  conv_out_below does not exist for a recomputed block: gamma == 0 channels as in the plain entry.
+extern "C" int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin) {
+    ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
+    return (p.kind == 1 && p.nct == 4 && dgrad_rg_lds(p) <= 80 * 1024) ? p.rows : 0;
+}
+extern "C" int sed_conv3x3_dgrad_bnred_rg(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
+                                          const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
+                                          const float* x1, const unsigned char* argmax_bits, float* rg_partials,
+                                          int B, int C, int F, int T, int Cin, void* stream) {
+    SED_REQUIRE(x1 && argmax_bits && rg_partials, "conv3x3_dgrad_bnred_rg: null pointer");
+    return dgrad_bnred_impl(dy, wp_dgrad, dx, partials, pooled, gamma, beta, nullptr, mean, rstd, drop_p, 1, 2, F, 2 * T,
+                            x1, argmax_bits, rg_partials, B, C, F, T, Cin, stream);
 }
 
 // ───────────────────────── weight gradient ─────────────────────────

@@ -885,6 +885,20 @@ extern "C" size_t sed_conv1_moments_doubles(int Cin) { const int nk = 9 * Cin; r
 static int c1_rgrad_rows(int B, int T) {          // (512 rows instead of 2048: the pass beside the weight gradient 1.14 -> 1.58 ms)
     return sed_conv1_fused_rows(B, T);
 }
+// The assembling half of sed_conv1_bwd_wgrad alone, from partial sums another kernel formed: partials [rows][C][1 + 9 Cin]
+// = (sum g, R_k) — sed_conv3x3_dgrad_bnred_rg writes them from the epilogue of the data gradient of the block above.
+extern "C" int sed_conv1_bwd_wgrad_assemble(const float* partials, int rows, const double* moments, const float* wp, const float* bias,
+                                            const float* mean, const float* rstd, const float* scale, const float* sum_g,
+                                            const float* sum_gx, float* dw_oihw, float* dbias, int B, int Cin, int F, int T, int C,
+                                            const float* gamma, const float* beta, float* dgamma, void* stream) {
+    SED_REQUIRE(partials && moments && wp && mean && rstd && scale && sum_g && sum_gx && dw_oihw && dbias, "conv1_bwd_wgrad_assemble: null pointer");
+    SED_REQUIRE(rows > 0 && B > 0 && Cin >= 1 && Cin <= 4 && F > 0 && T > 0 && C > 0, "conv1_bwd_wgrad_assemble: bad shape");
+    conv1_wgrad_assemble_k<<<C, 256, 0, as_stream(stream)>>>(partials, rows, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
+                                                             (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);
+    SED_LAUNCH_CHECK("conv1_wgrad_assemble");
+    return 0;
+}
+
 extern "C" size_t sed_conv1_bwd_wgrad_workspace_bytes(int B, int Cin, int T, int C) {
     return (size_t)c1_rgrad_rows(B, T) * (1 + 9 * Cin) * C * sizeof(float);
 }

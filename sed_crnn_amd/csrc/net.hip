@@ -11,6 +11,7 @@ namespace {
 
 struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop;
                int red_rows;      // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
+               int rg_rows;       // > 0 (block 0 only): so do its weight-gradient sums (sed_conv3x3_dgrad_bnred_rg), into c1_ws
                int rgrad; };      // recomputed first block: its weight gradient comes from the pooled output, arg-max bits and input moments   // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
 struct GruL { int in, H; };
 
@@ -108,6 +109,12 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         const int rr = (c->conv_mode == 0) ? sed_conv3x3_dgrad_bnred_rows(c->B, q.C, q.F, q.T, q.Cin) : 0;
         L->cv[l - 1].red_rows = rr;
         if (rr > max_bn_rows) max_bn_rows = rr;
+        // ... and, for the recomputed 1-channel first block, its weight-gradient sums too (10 floats per channel and workgroup)
+        if (l == 1 && rr > 0 && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin == 1) {
+            const int gr = sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin);
+            L->cv[0].rg_rows = gr;
+            if ((size_t)gr * q.Cin * 10 > c1_ws) c1_ws = (size_t)gr * q.Cin * 10;
+        }
     }
     L->c1_stat_ws = cv.take(c1_stat_ws);
     L->c1_bits = L->cv[0].rgrad ? cv.take(((size_t)c->B * L->cv[0].Tp * L->cv[0].Fp * (L->cv[0].C / 4) + 3) / 4) : 0;      // one byte per channel quad
@@ -394,7 +401,11 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
     }
     if (part & 2) {
         if (count_scale != 1.f) SED_TRY(sed_scale(sum_g, 2 * q.C, 1.f / count_scale, st));   // global sums / global count
-        if (q.fused && q.rgrad) {
+        if (q.fused && q.rgrad && q.rg_rows > 0) {         // the sums came out of the data gradient above: assemble only
+            SED_TRY(sed_conv1_bwd_wgrad_assemble(ws + L.c1_ws, q.rg_rows, (const double*)(ws + L.c1_mom), ws + L.wp_f[l], p->conv_b[l],
+                                                 ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
+                                                 B, q.Cin, q.F, q.T, q.C, p->bn_g[l], p->bn_b[l], g->bn_g[l], st));
+        } else if (q.fused && q.rgrad) {
             SED_TRY(sed_conv1_bwd_wgrad(x, ws + L.gradA, ws + L.pooled[l], (const unsigned char*)(ws + L.c1_bits), (const double*)(ws + L.c1_mom),
                                         ws + L.wp_f[l], p->conv_b[l], ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, sum_gx,
                                         g->conv_w[l], g->conv_b[l], ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.drop,
@@ -418,9 +429,13 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
 
 // data gradient of block l >= 1 into gradA; where the shapes allow it the epilogue also writes the BatchNorm-backward partial
 // sums of block l-1 into bn_part (cv[l-1].red_rows > 0), which bn_backward then only finalises
-static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, float* ws, int l, void* st) {
+static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, const float* x, float* ws, int l, void* st) {
     const ConvL& q = L.cv[l];
     const ConvL& u = L.cv[l - 1];
+    if (u.rg_rows > 0)
+        return sed_conv3x3_dgrad_bnred_rg(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
+                                          p->bn_g[l - 1], p->bn_b[l - 1], ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop,
+                                          x, (const unsigned char*)(ws + L.c1_bits), ws + L.c1_ws, c->B, q.C, q.F, q.T, q.Cin, st);
     if (u.red_rows > 0)
         return sed_conv3x3_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                        p->bn_g[l - 1], p->bn_b[l - 1],
@@ -592,7 +607,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             continue;
         }
         // data gradient = the same convolution with flipped, transposed taps (+ the BatchNorm-backward sums of the block below)
-        SED_TRY(dgrad(L, c, p, ws, l, stream));
+        SED_TRY(dgrad(L, c, p, x, ws, l, stream));
         if (l > 1) {
             if (top_wgrad_on_aux && l == top) {
                 // it starts here, beside BN(l-1) and then the next data gradient (config 2: step -65 us; started any
@@ -658,7 +673,7 @@ extern "C" int sed_net_backward_phases(const sed_net_cfg* c, const sed_net_param
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         SED_TRY(sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws),
                                      B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
-        if (l > 0) SED_TRY(dgrad(L, c, p, ws, l, stream));
+        if (l > 0) SED_TRY(dgrad(L, c, p, x, ws, l, stream));
     }
     return 0;
 }
