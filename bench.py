@@ -39,7 +39,7 @@ PROFILE_ROUNDS = ("r3", "r2", "r1")   # newest committed PMC summary first
 # the dominant kernel: conv2 / conv3 forward (<4, 2, false>) and their data gradients (<4, 2, true>: the same main loop with the
 # BatchNorm-backward reduction of the block below in its epilogue); one in-library timer tag covers both
 DOMINANT_KERNEL = "conv3x3_mfma_fwd2_k"
-DOMINANT_INSTANCES = ("conv3x3_mfma_fwd2_k<4, 2, false>", "conv3x3_mfma_fwd2_k<4, 2, true>", "conv3x3_mfma_fwd2_k<4, 2>")
+DOMINANT_PREFIX = "void conv3x3_mfma_fwd2_k<4, 2"      # every instantiation of the 128-channel tile: forward, data gradient (+ fused sums)
 
 
 def pmc_traffic_bytes():
@@ -54,9 +54,8 @@ def pmc_traffic_bytes():
         except Exception:
             continue
         tot, n = 0.0, 0
-        for inst in DOMINANT_INSTANCES:
-            e = d.get("void " + inst)
-            if e and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:
+        for name, e in d.items():
+            if name.startswith(DOMINANT_PREFIX) and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:
                 k = int(e.get("launches", 1))
                 tot += k * (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024
                 n += k
