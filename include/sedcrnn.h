@@ -102,15 +102,16 @@ int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, f
                             const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                             const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                             int B, int C, int F, int T, int Cin, void* stream);
-/* The same launch when the block below is the recomputed 1-channel first block with pool (1,2) (sed.py:86-92, ch = 1): the
- * epilogue also forms that block's weight-gradient sums — rg_partials [rows][Cin][10] = (sum g, R_0..R_8) per channel and
- * workgroup, R_{3kh+kw} = sum g~ x[f+kh-1][2t'+sel+kw-1] with sel the arg-max bit — from the network input x1 [B][1][F][2T] and
+/* The same launch when the block below is the recomputed first block with Cin1 = 1 or 2 input channels and pool (1,2)
+ * (sed.py:86-92, ch = 1 or 2): the epilogue also forms that block's weight-gradient sums — rg_partials [rows][Cin][1 + 9 Cin1]
+ * = (sum g, R_k) per channel and workgroup, R_{(3kh+kw) Cin1 + ci} = sum g~ x[ci][f+kh-1][2t'+sel+kw-1] with sel the arg-max
+ * bit — from the network input x1 [B][Cin1][F][2T] and
  * the arg-max bits of sed_conv1_bn_relu_pool_drop_fwd, for sed_conv1_bwd_wgrad_assemble.  Replaces the pass of
  * sed_conv1_bwd_wgrad over dx, the pooled tensor and the bits.  rows = sed_conv3x3_dgrad_bnred_rg_rows(); 0 = not supported. */
-int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin);
+int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin, int Cin1);
 int sed_conv3x3_dgrad_bnred_rg(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
                                const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
-                               const float* x1, const unsigned char* argmax_bits, float* rg_partials,
+                               const float* x1, int Cin1, const unsigned char* argmax_bits, float* rg_partials,
                                int B, int C, int F, int T, int Cin, void* stream);
 
 /* ───────────── BatchNorm2d + ReLU + MaxPool2d + Dropout (sed.py:89-92,107; crnn_lightning.py:48-52) ─────────────

@@ -60,8 +60,8 @@ SIGNATURES = {
     "sed_conv3x3_wgrad_ex": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_dgrad_bnred_rows": (_i, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_dgrad_bnred": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _stream]),
-    "sed_conv3x3_dgrad_bnred_rg_rows": (_i, [_i, _i, _i, _i, _i]),
-    "sed_conv3x3_dgrad_bnred_rg": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv3x3_dgrad_bnred_rg_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sed_conv3x3_dgrad_bnred_rg": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv1_fused_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "sed_conv1_fused_rows": (_i, [_i, _i]),
     "sed_conv1_stats_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -385,19 +385,20 @@ struct ConvBnRed {
     float keep, inv_keep;    // 1 - p, 1 / (1 - p)
     int pf, pt, Fy, Ty;      // pool and the extents of ybelow
     // RG (the block below is the recomputed 1-channel first block, pool (1,2)): also its weight-gradient sums, see the kernel
-    const float* x1;         // the network input [B][1][Fy][Ty]
+    const float* x1;         // the network input [B][RGC][Fy][Ty]
     const unsigned char* bits;   // arg-max bits of the block below: [B][T][F][Cout/4] bytes, bit e = channel 4q+e took the second time row
-    float* rgp;              // out: [rows][Cout][10] = (sum g, R_0..R_8) per workgroup
+    float* rgp;              // out: [rows][Cout][1 + 9 RGC] = (sum g, R_k) per workgroup
     float invXT;             // 1 / (2 TT + 2)
 };
 
-template <int NCT, int MINW, bool BNR = false, bool RG = false>
+template <int NCT, int MINW, bool BNR = false, int RGC = 0>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft,
     float invF, float invF2, ConvBnRed br = ConvBnRed{}) {
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
+    constexpr bool RG = RGC > 0;                       // the block below is the recomputed first block with RGC input channels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
@@ -466,7 +467,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         for (int i = tid; i < F2 * XT; i += 256) {
             const int ff = sed_fdiv(i, br.invXT), tt = i - ff * XT;
             const int f = f0 + ff - 1, t = 2 * t0 + tt - 1;
-            xs[i] = (f >= 0 && f < F && t >= 0 && t < br.Ty) ? br.x1[((size_t)b * F + f) * br.Ty + t] : 0.f;
+            const bool in = f >= 0 && f < F && t >= 0 && t < br.Ty;
+#pragma unroll
+            for (int ci = 0; ci < RGC; ++ci)
+                xs[ci * F2 * XT + i] = in ? br.x1[(((size_t)b * RGC + ci) * F + f) * br.Ty + t] : 0.f;
         }
     }
 
@@ -594,17 +598,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const char* const qb = BNR ? (const char*)(br.pooled + (size_t)b * T * F * Cout + co0 + ct * 32) : nullptr;
     // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3):
     // xhat = q (1-p)/gamma - beta/gamma = q * q_kr + q_nb
-    f32x4 q_beta = {0, 0, 0, 0}, q_rg = {0, 0, 0, 0}, q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    f32x4 q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     unsigned slowmask = 0;                           // bit e: gamma == 0 and beta > 0 (xhat from the conv output)
     if (BNR) {
         const int cb = co0 + ct * 32 + c4;
-        q_beta = *(const f32x4*)(br.beta + cb);
+        const f32x4 q_beta = *(const f32x4*)(br.beta + cb);
         const f32x4 gm = *(const f32x4*)(br.gamma + cb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            q_rg[e] = gm[e] != 0.f ? 1.0f / gm[e] : 0.f;
-            q_kr[e] = br.keep * q_rg[e];
-            q_nb[e] = -q_beta[e] * q_rg[e];
+            const float rg = gm[e] != 0.f ? 1.0f / gm[e] : 0.f;
+            q_kr[e] = br.keep * rg;
+            q_nb[e] = -q_beta[e] * rg;
             if (gm[e] == 0.f && q_beta[e] > 0.f) slowmask |= 1u << e;
         }
     }
@@ -613,9 +617,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // RG: the first block's weight-gradient sums R[kh*3+kw] = sum g~ x[f+kh-1][2t'+sel+kw-1] (sel = the arg-max bit), which
     // conv1_rgrad_k otherwise forms in a pass of its own over dx (this kernel's output), the pooled tensor and the bits: 750 MB
     // that trailed the last weight gradient by 0.13 ms.  Here dx and the pooled values are in registers already.
-    f32x4 R[9];
+    f32x4 R[RG ? 9 * RGC : 1];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = (f32x4){0, 0, 0, 0};
+    for (int k = 0; k < (RG ? 9 * RGC : 1); ++k) R[k] = (f32x4){0, 0, 0, 0};
     const unsigned char* const bq = RG ? br.bits + (size_t)b * T * F * (Cout >> 2) + ((co0 + ct * 32 + c4) >> 2) : nullptr;
     auto store_tiles = [&](auto checked) {
         constexpr bool CHK = decltype(checked)::value;
@@ -629,13 +633,16 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 unsigned bt[4] = {0, 0, 0, 0};
                 if (RG) {
                     xo = *(const u32x4*)(xofftab + mt * 32 + rq * 4);
+                    if (RGC < 2) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (!CHK || rr[k] != 0xFFFFFFFFu) bt[k] = bq[rr[k] >> 4];
+                        for (int k = 0; k < 4; ++k)
+                            if (!CHK || rr[k] != 0xFFFFFFFFu) bt[k] = bq[rr[k] >> 4];
+                    }
                 }
                 // BNR: this tile's pooled values, requested before the transpose so that they arrive under it
                 f32x4 pq[4];
-                if (BNR) {
+                constexpr bool PQ_EARLY = RGC < 2;      // two input channels: 18 tap accumulators leave no room for four prefetched rows
+                if (BNR && PQ_EARLY) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         pq[k] = (f32x4){0, 0, 0, 0};
@@ -670,6 +677,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 v = *(const f32x4*)(tsc + (rq + 8 * k) * 32 + c4);
                     const bool ok = !CHK || rr[k] != 0xFFFFFFFFu;
+                    if (BNR && !PQ_EARLY) {
+                        pq[k] = (f32x4){0, 0, 0, 0};
+                        if (ok) { pq[k] = *(const f32x4*)(qb + ro[k]); bt[k] = bq[rr[k] >> 4]; }
+                    }
                     if (ok) *(f32x4*)(yb + ro[k]) = v;
                     if (BNR && ok) {
                         // g = v / (1-p) where the pooled value is > 0; the 1 / (1-p) is applied to the sums at the end
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float pv = pq[k][e];
-                                float xh = (pv * br.keep - q_beta[e]) * q_rg[e];
+                                float xh = pv * q_kr[e] + q_nb[e];
                                 if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
                                     const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
                                     xh = 0.f;                 // (no stored conv output: the block's own apply pass supplies this dgamma)
@@ -703,13 +714,16 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
                             for (int e = 0; e < 4; ++e) g1[e] = ((bt[k] >> e) & 1u) ? g0[e] : 0.f;
                             const f32x4 gA = g0 - g1;
-                            const float* xb = xs + xo[k];
 #pragma unroll
-                            for (int kh = 0; kh < 3; ++kh) {
-                                const f32x2 x01 = *(const f32x2*)(xb + kh * XT), x23 = *(const f32x2*)(xb + kh * XT + 2);
-                                R[kh * 3 + 0] += gA * x01[0] + g1 * x01[1];
-                                R[kh * 3 + 1] += gA * x01[1] + g1 * x23[0];
-                                R[kh * 3 + 2] += gA * x23[0] + g1 * x23[1];
+                            for (int ci = 0; ci < RGC; ++ci) {
+                                const float* xb = xs + ci * F2 * XT + xo[k];
+#pragma unroll
+                                for (int kh = 0; kh < 3; ++kh) {
+                                    const f32x2 x01 = *(const f32x2*)(xb + kh * XT), x23 = *(const f32x2*)(xb + kh * XT + 2);
+                                    R[(kh * 3 + 0) * RGC + ci] += gA * x01[0] + g1 * x01[1];
+                                    R[(kh * 3 + 1) * RGC + ci] += gA * x01[1] + g1 * x23[0];
+                                    R[(kh * 3 + 2) * RGC + ci] += gA * x23[0] + g1 * x23[1];
+                                }
                             }
                         }
                     }
@@ -736,17 +750,17 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                 *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
                 *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
             }
-            if (RG) {                                 // [4 waves][9][32] behind `red`: this wave's 32 channels of R_0..R_8
+            if (RG) {                                 // [4 waves][9 RGC][32] behind `red`: this wave's 32 channels of the R_k
                 float* red2 = smem + 4 * 1024 + 256;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) {
+                for (int k = 0; k < 9 * RGC; ++k) {
                     R[k] *= br.inv_keep;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
 #pragma unroll
                         for (int o = 8; o < 64; o <<= 1) R[k][e] += __shfl_xor(R[k][e], o, 64);
                     }
-                    if (lane < 8) *(f32x4*)(red2 + (wave * 9 + k) * 32 + c4) = R[k];
+                    if (lane < 8) *(f32x4*)(red2 + (wave * 9 * RGC + k) * 32 + c4) = R[k];
                 }
             }
         } else {
@@ -768,11 +782,11 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         }
         if (RG && tid < WROWS) {                      // MPARTS == 1: wave ct owns channels 32 ct .. 32 ct + 31
             const int cti = tid >> 5, cr = tid & 31;
-            float* o = br.rgp + (row * Cout + co0 + tid) * 10;
+            float* o = br.rgp + (row * Cout + co0 + tid) * (1 + 9 * RGC);
             o[0] = red[(cti * 2 + 0) * 32 + cr];      // sum g (= the BatchNorm sum above)
             const float* red2 = smem + 4 * 1024 + 256;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) o[1 + k] = red2[(cti * 9 + k) * 32 + cr];
+            for (int k = 0; k < 9 * RGC; ++k) o[1 + k] = red2[(cti * 9 * RGC + k) * 32 + cr];
         }
     }
 }
@@ -1023,8 +1037,8 @@ static int set_lds(K kernel, size_t bytes) {
 }
 
 // LDS of the data gradient with the first block's weight-gradient sums: + the window-offset table + the input patch
-static size_t dgrad_rg_lds(const ConvPlan& p) {
-    return p.lds + (size_t)32 * CV_MTW * sizeof(unsigned) + ((size_t)(2 * p.TT + 2) * (p.FT + 2) + 4) * sizeof(float);
+static size_t dgrad_rg_lds(const ConvPlan& p, int cin1) {
+    return p.lds + (size_t)32 * CV_MTW * sizeof(unsigned) + ((size_t)cin1 * (2 * p.TT + 2) * (p.FT + 2) + 4) * sizeof(float);
 }
 
 extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
@@ -1110,7 +1124,7 @@ extern "C" int sed_conv3x3_dgrad_bnred_rows(int B, int C, int F, int T, int Cin)
 static int dgrad_bnred_impl(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
                             const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                             const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
-                            const float* x1, const unsigned char* bits, float* rg_partials,
+                            const float* x1, int cin1, const unsigned char* bits, float* rg_partials,
                             int B, int C, int F, int T, int Cin, void* stream) {
     SED_REQUIRE(dy && wp_dgrad && dx && partials && pooled && gamma && beta && mean && rstd, "conv3x3_dgrad_bnred: null pointer");
     SED_REQUIRE(B > 0 && C > 0 && F > 0 && T > 0 && Cin > 0, "conv3x3_dgrad_bnred: bad shape B=%d C=%d F=%d T=%d Cin=%d", B, C, F, T, Cin);
@@ -1132,12 +1146,18 @@ static int dgrad_bnred_impl(const float* dy, const float* wp_dgrad, float* dx, f
                  x1, bits, rg_partials, 1.0f / (float)(2 * p.TT + 2)};
     dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
     if (x1) {
-        const size_t lds = dgrad_rg_lds(p);
-        SED_REQUIRE(bits && rg_partials && pool_f == 1 && pool_t == 2 && Ty == 2 * T && lds <= 80 * 1024,
-                    "conv3x3_dgrad_bnred_rg: needs pool (1,2), an even conv time extent and a tile that leaves two workgroups per CU");
-        SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true, true>), lds));
-        conv3x3_mfma_fwd2_k<4, 2, true, true><<<grid, 256, lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
-                                                                    1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+        const size_t lds = dgrad_rg_lds(p, cin1);
+        SED_REQUIRE(bits && rg_partials && (cin1 == 1 || cin1 == 2) && pool_f == 1 && pool_t == 2 && Ty == 2 * T && lds <= 80 * 1024,
+                    "conv3x3_dgrad_bnred_rg: needs 1 or 2 input channels, pool (1,2), an even conv time extent and a tile that leaves two workgroups per CU");
+        if (cin1 == 1) {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true, 1>), lds));
+            conv3x3_mfma_fwd2_k<4, 2, true, 1><<<grid, 256, lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
+                                                                     1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+        } else {
+            SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true, 2>), lds));
+            conv3x3_mfma_fwd2_k<4, 2, true, 2><<<grid, 256, lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
+                                                                     1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2), br);
+        }
     } else {
         SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true>), p.lds));
         conv3x3_mfma_fwd2_k<4, 2, true><<<grid, 256, p.lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
@@ -1152,24 +1172,25 @@ extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, f
                                        const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                                        int B, int C, int F, int T, int Cin, void* stream) {
     return dgrad_bnred_impl(dy, wp_dgrad, dx, partials, pooled, gamma, beta, conv_out_below, mean, rstd, drop_p, pool_f, pool_t, Fy, Ty,
-                            nullptr, nullptr, nullptr, B, C, F, T, Cin, stream);
+                            nullptr, 0, nullptr, nullptr, B, C, F, T, Cin, stream);
 }
 
 // The same launch when the block below is the recomputed 1-channel first block with pool (1,2): the epilogue also forms that
-// block's weight-gradient sums (sum g, R_0..R_8 per channel and workgroup -> rg_partials [rows][Cin][10], rows =
-// sed_conv3x3_dgrad_bnred_rg_rows) from the network input x1 [B][1][F][2T] and the arg-max bits of its forward, for
+// block's weight-gradient sums (sum g, R_k per channel and workgroup -> rg_partials [rows][Cin][1 + 9 Cin1], rows =
+// sed_conv3x3_dgrad_bnred_rg_rows) from the network input x1 [B][Cin1][F][2T], Cin1 = 1 or 2, and the arg-max bits of its forward, for
 // sed_conv1_bwd_wgrad_assemble.  conv_out_below does not exist for a recomputed block: gamma == 0 channels as in the plain entry.
-extern "C" int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin) {
+extern "C" int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin, int Cin1) {
+    if (Cin1 < 1 || Cin1 > 2) return 0;
     ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
-    return (p.kind == 1 && p.nct == 4 && dgrad_rg_lds(p) <= 80 * 1024) ? p.rows : 0;
+    return (p.kind == 1 && p.nct == 4 && dgrad_rg_lds(p, Cin1) <= 80 * 1024) ? p.rows : 0;
 }
 extern "C" int sed_conv3x3_dgrad_bnred_rg(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
                                           const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
-                                          const float* x1, const unsigned char* argmax_bits, float* rg_partials,
+                                          const float* x1, int Cin1, const unsigned char* argmax_bits, float* rg_partials,
                                           int B, int C, int F, int T, int Cin, void* stream) {
     SED_REQUIRE(x1 && argmax_bits && rg_partials, "conv3x3_dgrad_bnred_rg: null pointer");
     return dgrad_bnred_impl(dy, wp_dgrad, dx, partials, pooled, gamma, beta, nullptr, mean, rstd, drop_p, 1, 2, F, 2 * T,
-                            x1, argmax_bits, rg_partials, B, C, F, T, Cin, stream);
+                            x1, Cin1, argmax_bits, rg_partials, B, C, F, T, Cin, stream);
 }
 
 // ───────────────────────── weight gradient ─────────────────────────

@@ -109,11 +109,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         const int rr = (c->conv_mode == 0) ? sed_conv3x3_dgrad_bnred_rows(c->B, q.C, q.F, q.T, q.Cin) : 0;
         L->cv[l - 1].red_rows = rr;
         if (rr > max_bn_rows) max_bn_rows = rr;
-        // ... and, for the recomputed 1-channel first block, its weight-gradient sums too (10 floats per channel and workgroup)
-        if (l == 1 && rr > 0 && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin == 1) {
-            const int gr = sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin);
+        // ... and, for the recomputed first block with 1 or 2 input channels, its weight-gradient sums too (1 + 9 Cin floats per
+        // channel and workgroup)
+        if (l == 1 && rr > 0 && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin <= 2) {
+            const int gr = sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin, L->cv[0].Cin);
             L->cv[0].rg_rows = gr;
-            if ((size_t)gr * q.Cin * 10 > c1_ws) c1_ws = (size_t)gr * q.Cin * 10;
+            const size_t need = (size_t)gr * q.Cin * (1 + 9 * L->cv[0].Cin);
+            if (need > c1_ws) c1_ws = need;
         }
     }
     L->c1_stat_ws = cv.take(c1_stat_ws);
@@ -435,7 +437,7 @@ static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p,
     if (u.rg_rows > 0)
         return sed_conv3x3_dgrad_bnred_rg(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                           p->bn_g[l - 1], p->bn_b[l - 1], ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop,
-                                          x, (const unsigned char*)(ws + L.c1_bits), ws + L.c1_ws, c->B, q.C, q.F, q.T, q.Cin, st);
+                                          x, u.Cin, (const unsigned char*)(ws + L.c1_bits), ws + L.c1_ws, c->B, q.C, q.F, q.T, q.Cin, st);
     if (u.red_rows > 0)
         return sed_conv3x3_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                        p->bn_g[l - 1], p->bn_b[l - 1],

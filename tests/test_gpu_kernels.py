@@ -300,20 +300,21 @@ def test_bn_backward_sums_of_the_gru_feeding_block_from_its_pooled_output(ops, B
     assert float(sum_gx[3].abs()) > 0.0
 
 
-@pytest.mark.parametrize("B,F,T,p", [(3, 40, 32, 0.5), (2, 40, 20, 0.0), (1, 40, 36, 0.5), (2, 24, 12, 0.3), (2, 128, 16, 0.5)])
-def test_first_block_weight_gradient_sums_from_the_data_gradient_epilogue(ops, B, F, T, p):
+@pytest.mark.parametrize("B,F,T,p,cin", [(3, 40, 32, 0.5, 1), (2, 40, 20, 0.0, 1), (1, 40, 36, 0.5, 1), (2, 24, 12, 0.3, 1), (2, 128, 16, 0.5, 1),
+                                          (3, 40, 32, 0.5, 2), (1, 40, 36, 0.0, 2), (2, 24, 12, 0.3, 2)])
+def test_first_block_weight_gradient_sums_from_the_data_gradient_epilogue(ops, B, F, T, p, cin):
     """sed_conv3x3_dgrad_bnred_rg + sed_conv1_bwd_wgrad_assemble against sed_conv3x3_dgrad_bnred + sed_conv1_bwd_wgrad: the
-    data gradient of block 2 whose epilogue also forms the 1-channel first block's weight-gradient sums (sum g, R_0..R_8) from
+    data gradient of block 2 whose epilogue also forms the 1- or 2-channel first block's weight-gradient sums (sum g, R_k) from
     the network input and the arg-max bits, instead of conv1_rgrad_k's pass over dx / pooled / bits.  dx and the BatchNorm
     partials bit for bit (same instructions), dW / dbias of the first block to rounding.  Edge tiles in time and mel (zero
     padding of the input patch), ragged tile counts, dropout on / off, gamma == 0 of both beta signs, negative gamma."""
     from sed_crnn_amd._lib import lib, ptr, check, stream_ptr
     L = lib()
     C = 128
-    gen = torch.Generator().manual_seed(B * 1000 + F * 10 + T)
+    gen = torch.Generator().manual_seed(B * 1000 + F * 10 + T + cin)
     g = lambda t: t.cuda()
-    x = torch.randn(B, 1, F, T, generator=gen)
-    w1 = torch.randn(C, 1, 3, 3, generator=gen) * 0.4
+    x = torch.randn(B, cin, F, T, generator=gen)
+    w1 = torch.randn(C, cin, 3, 3, generator=gen) * 0.4
     b1 = torch.randn(C, generator=gen) * 0.1
     gamma = torch.rand(C, generator=gen) + 0.5
     beta = torch.randn(C, generator=gen) * 0.3
@@ -322,21 +323,21 @@ def test_first_block_weight_gradient_sums_from_the_data_gradient_epilogue(ops, B
     gamma[64] = -0.8
     w2 = torch.randn(C, C, 3, 3, generator=gen) / np.sqrt(9 * C)
     Tp = T // 2
-    if not L.sed_conv3x3_dgrad_bnred_rg_rows(B, C, F, Tp, C):
+    if not L.sed_conv3x3_dgrad_bnred_rg_rows(B, C, F, Tp, C, cin):
         pytest.skip("shape does not take the fused path")
     dy = (torch.randn(B, Tp, F, C, generator=gen) * 0.1)
     seed = 11
     # forward of the first block (statistics from the input moments, arg-max bits)
     wf1, _ = ops.conv3x3_pack(g(w1))
     stat = torch.empty(1, 2, C).cuda()
-    sws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, 1, T) // 4 + 1).cuda()
-    mom = torch.empty(L.sed_conv1_moments_doubles(1), dtype=torch.float64).cuda()
+    sws = torch.empty(L.sed_conv1_stats_workspace_bytes(B, cin, T) // 4 + 1).cuda()
+    mom = torch.empty(L.sed_conv1_moments_doubles(cin), dtype=torch.float64).cuda()
     xg, b1g, gg, bg = g(x), g(b1), g(gamma), g(beta)
-    check(L.sed_conv1_stats(ptr(xg), ptr(wf1), ptr(b1g), ptr(stat), ptr(sws), B, 1, F, T, C, ptr(mom), stream_ptr()), "conv1_stats")
+    check(L.sed_conv1_stats(ptr(xg), ptr(wf1), ptr(b1g), ptr(stat), ptr(sws), B, cin, F, T, C, ptr(mom), stream_ptr()), "conv1_stats")
     mean, rstd, scale, shift = ops.bn_finalize_train(stat, B * T * F, gg, bg, torch.zeros(C).cuda(), torch.ones(C).cuda())
     pooled = torch.empty(B, Tp, F, C).cuda()
     bits = torch.empty(pooled.numel() // 4, dtype=torch.uint8).cuda()
-    check(L.sed_conv1_bn_relu_pool_drop_fwd(ptr(xg), ptr(wf1), ptr(b1g), ptr(scale), ptr(shift), ptr(pooled), B, 1, F, T, C, 1, 2, p, seed,
+    check(L.sed_conv1_bn_relu_pool_drop_fwd(ptr(xg), ptr(wf1), ptr(b1g), ptr(scale), ptr(shift), ptr(pooled), B, cin, F, T, C, 1, 2, p, seed,
                                             None, ptr(bits), stream_ptr()), "conv1_fwd")
     _, wd2 = ops.conv3x3_pack(g(w2))
     dyg = g(dy)
@@ -352,22 +353,22 @@ def test_first_block_weight_gradient_sums_from_the_data_gradient_epilogue(ops, B
     check(L.sed_conv3x3_dgrad_bnred(ptr(dyg), ptr(wd2), ptr(dx_a), ptr(part_a), ptr(pooled), ptr(gg), ptr(bg), None, ptr(mean), ptr(rstd),
                                     p, 1, 2, F, T, B, C, F, Tp, C, stream_ptr()), "dgrad_bnred")
     sg_a, sgx_a, dgam_a, _ = finish(part_a, rows)
-    dw_a, db_a = torch.empty(C, 1, 3, 3).cuda(), torch.empty(C).cuda()
-    ws = torch.empty(L.sed_conv1_bwd_wgrad_workspace_bytes(B, 1, T, C) // 4 + 1).cuda()
+    dw_a, db_a = torch.empty(C, cin, 3, 3).cuda(), torch.empty(C).cuda()
+    ws = torch.empty(L.sed_conv1_bwd_wgrad_workspace_bytes(B, cin, T, C) // 4 + 1).cuda()
     check(L.sed_conv1_bwd_wgrad(ptr(xg), ptr(dx_a), ptr(pooled), ptr(bits), ptr(mom), ptr(wf1), ptr(b1g), ptr(mean), ptr(rstd), ptr(scale),
-                                ptr(sg_a), ptr(sgx_a), ptr(dw_a), ptr(db_a), ptr(ws), B, 1, F, T, C, p, ptr(gg), ptr(bg), ptr(dgam_a),
+                                ptr(sg_a), ptr(sgx_a), ptr(dw_a), ptr(db_a), ptr(ws), B, cin, F, T, C, p, ptr(gg), ptr(bg), ptr(dgam_a),
                                 stream_ptr()), "conv1_bwd_wgrad")
     # fused: the sums come out of the data gradient's epilogue
-    rows_b = L.sed_conv3x3_dgrad_bnred_rg_rows(B, C, F, Tp, C)
+    rows_b = L.sed_conv3x3_dgrad_bnred_rg_rows(B, C, F, Tp, C, cin)
     assert rows_b == rows
     dx_b, part_b = torch.empty(B, Tp, F, C).cuda(), torch.empty(rows, 2, C).cuda()
-    rgp = torch.full((rows, C, 10), float("nan")).cuda()
+    rgp = torch.full((rows, C, 1 + 9 * cin), float("nan")).cuda()
     check(L.sed_conv3x3_dgrad_bnred_rg(ptr(dyg), ptr(wd2), ptr(dx_b), ptr(part_b), ptr(pooled), ptr(gg), ptr(bg), ptr(mean), ptr(rstd), p,
-                                       ptr(xg), ptr(bits), ptr(rgp), B, C, F, Tp, C, stream_ptr()), "dgrad_bnred_rg")
+                                       ptr(xg), cin, ptr(bits), ptr(rgp), B, C, F, Tp, C, stream_ptr()), "dgrad_bnred_rg")
     sg_b, sgx_b, dgam_b, _ = finish(part_b, rows)
-    dw_b, db_b = torch.empty(C, 1, 3, 3).cuda(), torch.empty(C).cuda()
+    dw_b, db_b = torch.empty(C, cin, 3, 3).cuda(), torch.empty(C).cuda()
     check(L.sed_conv1_bwd_wgrad_assemble(ptr(rgp), rows, ptr(mom), ptr(wf1), ptr(b1g), ptr(mean), ptr(rstd), ptr(scale), ptr(sg_b), ptr(sgx_b),
-                                         ptr(dw_b), ptr(db_b), B, 1, F, T, C, ptr(gg), ptr(bg), ptr(dgam_b), stream_ptr()), "assemble")
+                                         ptr(dw_b), ptr(db_b), B, cin, F, T, C, ptr(gg), ptr(bg), ptr(dgam_b), stream_ptr()), "assemble")
     assert torch.equal(dx_a, dx_b) and torch.equal(part_a, part_b)
     assert bool(torch.isfinite(rgp).all())
     mag = float(dw_a.abs().max())
