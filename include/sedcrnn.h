@@ -83,7 +83,13 @@ size_t sed_conv3x3_wgrad_workspace_bytes(int B, int Cin, int F, int T, int Cout)
 int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                       void* workspace, int B, int Cin, int F, int T, int Cout, void* stream);
 
-/* mode 1 (EXPERIMENT, as sed_conv3x3_fwd_ex): the MFMA path on the 3-term bf16 split; other shapes run mode 0. */
+/* mode 1 (EXPERIMENT, as sed_conv3x3_fwd_ex): the MFMA path on the 3-term bf16 split; other shapes run mode 0.
+ * mode | SED_WGRAD_ZERO_ROW_CLEAN: the exact-fp32 MFMA kernel reads out-of-image rows from a zero-filled row at the START of
+ * the workspace (sed_conv3x3_wgrad_zero_row_bytes(), 0 for shapes that have none), which the entry clears with a memset on
+ * `stream` in every call — unless this flag says the caller keeps those bytes zero (nothing ever writes them): a plan that
+ * calls the entry every step clears them once, off its critical chain, and saves the memset node in front of each launch. */
+#define SED_WGRAD_ZERO_ROW_CLEAN 0x100
+size_t sed_conv3x3_wgrad_zero_row_bytes(int B, int Cin, int F, int T, int Cout);
 int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                          void* workspace, int B, int Cin, int F, int T, int Cout, int mode, void* stream);
 

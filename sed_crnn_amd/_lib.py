@@ -56,6 +56,7 @@ SIGNATURES = {
     "sed_conv3x3_pack_weights_ex": (_i, [_fp, _fp, _fp, _i, _i, _i, _stream]),
     "sed_conv3x3_fwd_ex": (_i, [_fp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "sed_conv3x3_wgrad_zero_row_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_wgrad": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wgrad_ex": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_dgrad_bnred_rows": (_i, [_i, _i, _i, _i, _i]),

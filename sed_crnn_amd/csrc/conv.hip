@@ -1254,7 +1254,7 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
     p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
     // the position-contiguous kernel reads rows outside the image from a zero-filled row behind the slabs
-    p.zrow_floats = p.v2 ? (size_t)(p.FT + 4) * (Cin > Cout ? Cin : Cout) + 64 : 0;
+    p.zrow_floats = p.v2 ? (((size_t)(p.FT + 4) * (Cin > Cout ? Cin : Cout) + 64 + 63) / 64) * 64 : 0;      // at the START of the workspace
     return p;
 }
 
@@ -1915,6 +1915,11 @@ __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float*
     dw[((size_t)co * Cin + ci) * 9 + tap] = a;
 }
 
+extern "C" size_t sed_conv3x3_wgrad_zero_row_bytes(int B, int Cin, int F, int T, int Cout) {
+    if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
+    return wgrad_plan(B, Cin, F, T, Cout, 0, 0).zrow_floats * sizeof(float);
+}
+
 extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
                                  int B, int Cin, int F, int T, int Cout, void* stream) {
     return sed_conv3x3_wgrad_ex(x, x_is_nchw, dy, dw, workspace, B, Cin, F, T, Cout, 0, stream);
@@ -1923,11 +1928,13 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
 extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
                                     int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
     SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
+    const bool zero_row_clean = (mode & SED_WGRAD_ZERO_ROW_CLEAN) != 0;      // the caller cleared sed_conv3x3_wgrad_zero_row_bytes()
+    mode &= ~SED_WGRAD_ZERO_ROW_CLEAN;
     SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_wgrad: unknown mode %d", mode);
     SED_REQUIRE(Cout % 4 == 0, "conv3x3_wgrad: Cout must be a multiple of 4 (got %d)", Cout);
     WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
     hipStream_t s = as_stream(stream);
-    float* slabs = (float*)workspace;
+    float* slabs = (float*)workspace + p.zrow_floats;      // [zero row (exact-fp32 position-contiguous kernel only)][slabs]
     int n = Cin * 9 * Cout;
     const double npos = (double)B * T * F;
     SedProfScope prof(p.kind == 1 ? SED_K_CONV_MFMA_WGRAD : SED_K_CONV_SMALL_WGRAD, s,
@@ -1947,9 +1954,11 @@ extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* 
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     } else if (p.kind == 1 && p.v2) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
-        float* zrow = slabs + p.slab_floats;
-        hipError_t e = hipMemsetAsync(zrow, 0, p.zrow_floats * sizeof(float), s);
-        if (e != hipSuccess) { sed_set_error("conv3x3_wgrad: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        float* zrow = (float*)workspace;
+        if (!zero_row_clean) {
+            hipError_t e = hipMemsetAsync(zrow, 0, p.zrow_floats * sizeof(float), s);
+            if (e != hipSuccess) { sed_set_error("conv3x3_wgrad: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        }
         if (p.FT == 40) {
             SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<40>, p.lds));
             conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles);

@@ -27,6 +27,7 @@ struct Layout {
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
+    size_t wgrad_zrow;       // floats at the start of wgrad_ws / wgrad_ws_aux that the backward keeps zero (sed_conv3x3_wgrad_zero_row_bytes)
     size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, wgrad_ws_aux, c1_ws, dgi[SED_MAX_GRU], dgh[SED_MAX_GRU], gru_bws, dgout[SED_MAX_GRU];
     size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws, gemm_ws_aux;
     size_t total;     // floats
@@ -95,6 +96,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
             if (sws > c1_stat_ws) c1_stat_ws = sws;
         } else {
             size_t wg = sed_conv3x3_wgrad_workspace_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float);
+            // the shared zero row: kept clean by the backward only when every block that shares the workspace has the same
+            // one (a block without it, or with a shorter one, would put its slabs on top of the others' zero row)
+            if (l > 0) {
+                const size_t zr = c->conv_mode == 0 ? sed_conv3x3_wgrad_zero_row_bytes(c->B, q.Cin, q.F, q.T, q.C) / sizeof(float) : 0;
+                if (l == 1) L->wgrad_zrow = zr;
+                else if (zr != L->wgrad_zrow) L->wgrad_zrow = 0;
+            }
             // block 0's weight gradient runs on the auxiliary stream beside the MFMA weight gradients: its own scratch
             if (l == 0 && c->n_conv > 1) c1_ws = wg + 64;
             else if (wg > max_wgrad) max_wgrad = wg;
@@ -457,8 +465,9 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     constexpr int kMaxDev = 16;
     static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
     // [i]: recurrence of GRU layer i done (main); [SED_MAX_GRU]: the GRU weight gradients of the aux stream done;
-    // [SED_MAX_GRU + 1]: data gradient of the top conv block issued (main); [SED_MAX_GRU + 2]: its weight gradient done (aux)
-    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 3] = {};
+    // [SED_MAX_GRU + 1]: data gradient of the top conv block issued (main); [SED_MAX_GRU + 2]: its weight gradient done (aux);
+    // [SED_MAX_GRU + 3]: the zero rows of the weight-gradient workspaces cleared (aux)
+    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 4] = {};
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
     hipEvent_t* ev_dg = nullptr;
     hipEvent_t* ev_bn = nullptr;
@@ -472,7 +481,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         ev_dg = ev_all[dev][0];
         ev_bn = ev_all[dev][1];
         ev_gru = ev_gru_all[dev];
-        for (int i = 0; i < SED_MAX_GRU + 3; ++i)
+        for (int i = 0; i < SED_MAX_GRU + 4; ++i)
             if (!ev_gru[i] && hipEventCreateWithFlags(&ev_gru[i], hipEventDisableTiming) != hipSuccess) {
                 sed_set_error("net_backward: hipEventCreate failed");
                 return SED_EINVAL;
@@ -494,6 +503,18 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 "net_backward: bad stage range [%d,%d)", stage_begin, stage_end);
     float* ws = (float*)workspace;
     const int B = c->B, M = L.M;
+
+    // The exact-fp32 weight-gradient kernel reads out-of-image rows from a zero-filled row at the start of its workspace.  Nothing
+    // writes those bytes, so this call clears them once, on the auxiliary stream where it costs the critical chain nothing, and
+    // passes SED_WGRAD_ZERO_ROW_CLEAN: the memset node in front of each weight gradient is gone (two per step, one of them on
+    // the chain; the top block's weight gradient also starts 6 us earlier and now gets its CUs before the BatchNorm apply pass
+    // below it — it shares the machine with that HBM-bound pass instead of with the MFMA data gradient: step -15 us).
+    const int wg_clean = (L.wgrad_zrow > 0 && s_aux) ? SED_WGRAD_ZERO_ROW_CLEAN : 0;
+    if (wg_clean) {
+        (void)hipMemsetAsync(ws + L.wgrad_ws, 0, L.wgrad_zrow * sizeof(float), s_aux);
+        (void)hipMemsetAsync(ws + L.wgrad_ws_aux, 0, L.wgrad_zrow * sizeof(float), s_aux);
+        (void)hipEventRecord(ev_gru[SED_MAX_GRU + 3], s_aux);
+    }
 
     if (stage_begin == 0) {
         // ── dense head ──
@@ -585,7 +606,8 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         const ConvL& q = L.cv[l];
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         float* scratch = ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws);
-        return sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, st);
+        if (l > 0 && wg_clean && st != aux_stream) (void)hipStreamWaitEvent(as_stream(st), ev_gru[SED_MAX_GRU + 3], 0);
+        return sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, (l > 0) ? (c->conv_mode | wg_clean) : 0, st);
     };
     auto wgrad = [&](int l) -> int { return wgrad_on(l, stream); };
     // an unfused first block (Cin > 2): its HBM-bound weight gradient follows its BatchNorm backward on the same stream, so with
@@ -616,7 +638,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 // earlier, beside dgrad(top), +80 us)
                 (void)hipEventRecord(ev_gru[SED_MAX_GRU + 1], s_main);
                 (void)hipStreamWaitEvent(s_aux, ev_gru[SED_MAX_GRU + 1], 0);
-                SED_TRY(sed_conv3x3_wgrad_ex(ws + L.pooled[l - 1], q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws_aux, B, q.Cin, q.F, q.T, q.C, c->conv_mode, aux_stream));
+                SED_TRY(sed_conv3x3_wgrad_ex(ws + L.pooled[l - 1], q.nchw, ws + L.dconv[l], g->conv_w[l], ws + L.wgrad_ws_aux, B, q.Cin, q.F, q.T, q.C, c->conv_mode | wg_clean, aux_stream));
                 (void)hipEventRecord(ev_gru[SED_MAX_GRU + 2], s_aux);
             }
             SED_TRY(bn_passes(l - 1, stream));
