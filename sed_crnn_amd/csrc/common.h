@@ -50,6 +50,10 @@ struct SedProfScope {
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
                                  void* stream);
 
+// internal (misc.hip): one wave that idles for `us` microseconds (<= 100) on `stream` — used to let a kernel on another stream,
+// released by the same event, reach the CUs first (see sed_net_backward)
+int sed_internal_stream_delay(int us, void* stream);
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

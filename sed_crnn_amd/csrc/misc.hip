@@ -172,6 +172,18 @@ extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long 
 // captured hipGraph of the step draws fresh dropout masks and uses the right Adam bias correction on every replay
 __global__ void step_advance_k(uint64_t* st) { st[0] += 1; st[1] += 1; }
 
+__global__ void stream_delay_k(unsigned ticks) {          // s_memrealtime runs at 100 MHz
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+int sed_internal_stream_delay(int us, void* stream) {
+    if (us <= 0) return 0;
+    if (us > 100) us = 100;
+    stream_delay_k<<<1, 64, 0, as_stream(stream)>>>((unsigned)us * 100u);
+    SED_LAUNCH_CHECK("stream_delay");
+    return 0;
+}
+
 extern "C" int sed_step_advance(uint64_t* state2, void* stream) {
     SED_REQUIRE(state2, "step_advance: null pointer");
     step_advance_k<<<1, 1, 0, as_stream(stream)>>>(state2);

@@ -606,7 +606,6 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         const ConvL& q = L.cv[l];
         const float* xin = (l == 0) ? x : ws + L.pooled[l - 1];
         float* scratch = ws + ((l == 0 && L.n_conv > 1) ? L.c1_ws : L.wgrad_ws);
-        if (l > 0 && wg_clean && st != aux_stream) (void)hipStreamWaitEvent(as_stream(st), ev_gru[SED_MAX_GRU + 3], 0);
         return sed_conv3x3_wgrad_ex(xin, q.nchw, ws + L.dconv[l], g->conv_w[l], scratch, B, q.Cin, q.F, q.T, q.C, (l > 0) ? (c->conv_mode | wg_clean) : 0, st);
     };
     auto wgrad = [&](int l) -> int { return wgrad_on(l, stream); };
@@ -630,6 +629,10 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             if (!q.fused && !wg0_with_bn) SED_TRY(wgrad(0));     // fused block 0: its BN pass already produced every gradient
             continue;
         }
+        // (the zero rows were cleared on the auxiliary stream at the top of this call: ordered here, far from the launches
+        // that read them — a wait right in front of the last weight gradient let the first block's pass on the auxiliary
+        // stream reach the CUs first, see below)
+        if (wg_clean) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU + 3], 0);
         // data gradient = the same convolution with flipped, transposed taps (+ the BatchNorm-backward sums of the block below)
         SED_TRY(dgrad(L, c, p, x, ws, l, stream));
         if (l > 1) {
@@ -652,6 +655,12 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             if (fin_on_main) SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, 1, 1.f, stream));
             (void)hipEventRecord(ev_dg[0], s_main);
             (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
+            // The first block's passes and the weight gradient issued below on the main stream are released by the same event;
+            // the persistent MFMA kernel must get the CUs FIRST (the passes then move in beside it): the other way round its
+            // workgroups wait for the passes' workgroups to retire — config 5: 8.6 -> 16.8 ms for that kernel, 62 -> 69 ms per
+            // step, decided by a microsecond (it used to be decided by the memset node that is gone now).  A 20 us idle wave
+            // in front of the auxiliary chain makes it deterministic; that chain has a millisecond of slack.
+            SED_TRY(sed_internal_stream_delay(20, aux_stream));
             SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, fin_on_main ? 2 : 3, 1.f, aux_stream));
             if (wg0_with_bn) SED_TRY(wgrad_on(0, aux_stream));
             (void)hipEventRecord(ev_bn[0], s_aux);
