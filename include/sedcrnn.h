@@ -158,6 +158,12 @@ int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, const float* s
  *          dropout, max-pool arg-max (first maximum wins) and ReLU;
  *  apply : dy = scale*(g - sum_g/N - xhat*sum_gx/N); also dgamma = sum_gx, dbeta = sum_g and
  *          the conv-bias gradient partials sum dy.  Fixed-order reductions. */
+/* The routing DECISIONS of the block, as the forward and backward kernels make them (z = y*scale + shift, first maximum of a
+ * window wins like max_pool2d, ReLU gate = max > 0; sed.py:107 `pool(torch.relu(bn(conv(x))))`): route [B][T/pt][F/pf][C], one
+ * byte per pooled element, 0 = gate closed, 1 + w = window element w = df*pool_t + dt.  Inspection / parity tests: an oracle that
+ * routes its gradient with these decisions differs from the kernels by rounding only.  pool_f*pool_t <= 254. */
+int sed_bn_relu_pool_route(const float* y, const float* scale, const float* shift, unsigned char* route,
+                           int B, int T, int F, int C, int pool_f, int pool_t, void* stream);
 int sed_bn_bwd_rows(int B, int T, int pool_t);   /* partial rows written by the two passes below */
 int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const float* scale,
                                      const float* shift, const float* mean, const float* rstd,
@@ -205,6 +211,9 @@ int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, const float
                                     const float* shift, float* out, int B, int Cin, int F, int T, int C,
                                     int pool_f, int pool_t, float drop_p, uint64_t seed, const uint64_t* seed_dev,
                                     unsigned char* argmax_bits, void* stream);
+/* sed_bn_relu_pool_route for the recomputed first block (the decisions of its passes; same shapes as the forward entry). */
+int sed_conv1_route(const float* x, const float* wp, const float* bias, const float* scale, const float* shift,
+                    unsigned char* route, int B, int Cin, int F, int T, int C, int pool_f, int pool_t, void* stream);
 int sed_conv1_bwd_reduce(const float* x, const float* wp, const float* bias, const float* dout,
                          const float* scale, const float* shift, const float* mean, const float* rstd,
                          float* partials, int B, int Cin, int F, int T, int C, int pool_f, int pool_t,
@@ -380,7 +389,15 @@ typedef struct sed_net_cfg {
     float bn_eps, bn_momentum;
     int conv_mode;                    /* 0 = exact fp32 (default); 1 = EXPERIMENT: conv forward, data gradient and weight gradient of the
                                          MFMA blocks on the 3-term bf16 split (sed_conv3x3_fwd_ex / sed_conv3x3_wgrad_ex) */
+    int flags;                        /* 0 (default) | SED_NET_* below: measurement / test switches of the backward schedule */
 } sed_net_cfg;
+/* The last backward phase runs the first block's passes (auxiliary stream) BESIDE the deferred MFMA weight gradients (main
+ * stream); the persistent MFMA kernel must hold its CUs before the passes move in.  That order is a DEPENDENCY: the kernel's
+ * workgroups announce themselves on a counter in the workspace and a one-wave gate at the head of the auxiliary chain waits
+ * for them.  SED_NET_AUX_FIRST (tests): the host enqueues the auxiliary chain before the main-stream kernel — the adversarial
+ * order, which must give the same gradients at the same speed.  SED_NET_NO_GATE (A/B measurements): no gate. */
+#define SED_NET_AUX_FIRST 0x1
+#define SED_NET_NO_GATE 0x2
 
 typedef struct sed_net_params {      /* pointers in the reference's own layouts */
     float* conv_w[SED_MAX_CONV];      /* [C][Cin][3][3] */
@@ -451,10 +468,20 @@ int sed_net_backward_phases(const sed_net_cfg* cfg, const sed_net_params* p, con
  *   "mean" / "rstd" / "scale" / "shift"[l] the batch statistics and fused BatchNorm coefficients of block l ([C]);
  *   "gi"[i] / "gru_out"[i] input projections [M][2][3H] and outputs [M][2H] of GRU layer i;
  *   training only: "dconv"[l] gradient of block l's conv output, "dgru_out"[i], "grad_act"[0] the buffer that carries the
- *   gradient of the pooled output being back-propagated (reused from block to block), "bn_sums_bwd"[0] (sum g, sum g*xhat).
+ *   gradient of the pooled output being back-propagated (reused from block to block), "bn_sums_bwd"[0] (sum g, sum g*xhat),
+ *   "wgrad_zero_row"[0|1] the zero-filled rows at the head of the weight-gradient scratch of the main / auxiliary stream
+ *   (SED_WGRAD_ZERO_ROW_CLEAN: sed_net_backward re-clears them in every call that holds stage 0).
  * <0: unknown name / index for this plan. */
 int sed_net_workspace_region(const sed_net_cfg* cfg, int training, const char* name, int index,
                              size_t* offset_bytes, size_t* n_floats);
+
+/* The ReLU-gate / arg-max decisions (codes of sed_bn_relu_pool_route) of conv block `block` in the last TRAINING forward that
+ * ran on `workspace` with input `x`; route: caller-owned [B][T_l/pt][F_l/pf][C] bytes.  Dispatches to sed_bn_relu_pool_route
+ * (stored conv output) or sed_conv1_route (recomputed first block: it re-reads p->conv_b, so call this before the optimiser
+ * moves the parameters).  For the parity tests of the gradient routing of
+ * `loss.backward()` (sed.py:137): see oracle/crnn_ref.py forward_routed. */
+int sed_net_routing(const sed_net_cfg* cfg, const sed_net_params* p, const float* x, const void* workspace, int block,
+                    unsigned char* route, void* stream);
 
 /* ───────────── in-library kernel timers — MEASUREMENT ONLY, off by default ─────────────
  * The one exception to the conventions at the top of this header: this group keeps process-wide mutable state (the

@@ -106,11 +106,98 @@ def forward_with_masks(model, x, masks):
     return model.fc(x)
 
 
-def fit_step_with_masks(model, optimizer, x, y, masks, loss_fn=bce_logits):
-    """fit_step (sed.py:134-137) through forward_with_masks"""
+# ── gradient routing with GIVEN decisions ──────────────────────────────────────────────────────────────────────────────
+# `pool(torch.relu(bn(conv(x))))` (sed.py:107; crnn_lightning.py:49-50) is piecewise linear: its backward sends the gradient of a
+# pooled element to ONE element of the window (the first maximum) if that maximum is > 0.  Which element, and whether the
+# gate is open, are DECISIONS on the BatchNorm output z; two correct fp32 implementations round z differently (~1e-7), so at
+# 10^7..10^9 elements a few decisions differ, and one differing gate moves its channel's cancelling sum of gradients by a whole
+# |g|.  To compare two implementations to ROUNDING, the functions below run the reference's forward with the decisions of the
+# other implementation injected (as `forward_with_masks` does for the dropout draw); `audit_routes` checks first that every
+# injected decision is one the reference arithmetic could have taken itself (a tie to within `tol`), so a kernel that routed
+# to a wrong element is reported, not followed.
+
+def route_mask(code, pf, pt, F, T, dtype=torch.float32):
+    """code: uint8 [B,Tp,Fp,C] (0 = ReLU gate closed, 1 + w = the gradient goes to window element w = df*pt + dt, the
+    row-major (F, T) window order of nn.MaxPool2d) -> R [B,C,F,T] of {0,1}: 1 on the routed element of every open window,
+    0 elsewhere (incl. the ragged tail that floor pooling drops)."""
+    B, Tp, Fp, C = code.shape
+    cc = code.permute(0, 3, 2, 1)                                   # [B,C,Fp,Tp]
+    R = torch.zeros(B, C, F, T, dtype=dtype)
+    for df in range(pf):
+        for dt in range(pt):
+            R[:, :, df:Fp * pf:pf, dt:Tp * pt:pt] = (cc == 1 + df * pt + dt).to(dtype)
+    return R
+
+
+def routed_relu_pool(z, R, pf, pt):
+    """relu + max_pool2d((pf,pt)) of z [B,C,F,T] with the window element and gate GIVEN by R (route_mask): the value of the
+    routed element (0 for a closed gate); autograd then sends the pooled gradient to exactly that element."""
+    B, C, F, T = z.shape
+    Fp, Tp = F // pf, T // pt
+    return (z * R)[:, :, :Fp * pf, :Tp * pt].reshape(B, C, Fp, pf, Tp, pt).sum((3, 5))      # at most one non-zero per window
+
+
+def audit_routes(z, code, pf, pt, tol=2e-5):
+    """Are the injected decisions ones this arithmetic could have taken?  z: the reference's own BatchNorm output [B,C,F,T].
+    Returns (gates that differ, arg-maxima that differ, worst shortfall): a differing gate must have |max z| <= tol and a
+    differing arg-max must pick an element within tol of the window maximum, else AssertionError."""
+    B, C, F, T = z.shape
+    Fp, Tp = F // pf, T // pt
+    w = z.detach()[:, :, :Fp * pf, :Tp * pt].reshape(B, C, Fp, pf, Tp, pt).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Fp, Tp, pf * pt)
+    zmax = w.max(-1).values
+    cc = code.permute(0, 3, 2, 1).long()                             # [B,C,Fp,Tp]
+    gate_h = cc > 0
+    gate_diff = gate_h != (zmax > 0)
+    worst = float(zmax[gate_diff].abs().max()) if bool(gate_diff.any()) else 0.0
+    assert worst <= tol, f"a ReLU gate was decided differently where |max z| = {worst:.3e} (not a tie)"
+    picked = w.gather(-1, (cc - 1).clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    short = torch.where(gate_h, zmax - picked, torch.zeros_like(zmax))
+    first = (w == zmax.unsqueeze(-1)).float().argmax(-1)             # first maximum, like max_pool2d
+    arg_diff = gate_h & (zmax > 0) & (first != cc - 1)
+    ws = float(short.max())
+    assert ws <= tol * max(1.0, float(zmax.abs().max())), f"an arg-max was routed to an element {ws:.3e} below the window maximum (not a tie)"
+    return int(gate_diff.sum()), int(arg_diff.sum()), max(worst, ws)
+
+
+def _blocks(model):
+    """(conv, bn, (pf, pt)) per block + the trailing dropout module of either reference variant"""
+    if hasattr(model, "convs"):
+        return [(c, b, (1, p)) for c, b, p in zip(model.convs, model.bns, model.time_pool)], model.drop, True
+    mods = list(model.conv_stack)
+    blocks = [(mods[i], mods[i + 1], tuple(mods[i + 3].kernel_size)) for i in range(0, len(mods) - 1, 4)]
+    return blocks, mods[-1], False
+
+
+def forward_routed(model, x, routes, masks=None, audit=None):
+    """SedNetRef.forward (sed.py:106-112) / LightningNetRef.forward (crnn_lightning.py:66-73) with the ReLU-gate and pooling
+    arg-max decisions of every block GIVEN (routes[l]: uint8 codes [B,Tp,Fp,C], see route_mask) and, optionally, the dropout
+    draw given too (masks[l], as in forward_with_masks; otherwise the model's own nn.Dropout runs).  `audit`: a list that
+    receives audit_routes' result per block."""
+    blocks, drop, every = _blocks(model)
+    for l, (conv, bn, (pf, pt)) in enumerate(blocks):
+        z = bn(conv(x))
+        if audit is not None:
+            audit.append(audit_routes(z, routes[l], pf, pt))
+        x = routed_relu_pool(z, route_mask(routes[l], pf, pt, z.shape[2], z.shape[3], z.dtype), pf, pt)
+        if masks is not None:
+            x = x * masks[l]
+        elif every or l == len(blocks) - 1:
+            x = drop(x)
+    b, c, f, t = x.shape
+    x = x.permute(0, 3, 1, 2).reshape(b, t, c * f)
+    if hasattr(model, "gru"):
+        x, _ = model.gru(x)
+        return model.fc(x)
+    x, _ = model.gru1(x)
+    x, _ = model.gru2(x)
+    return model.d2(torch.relu(model.d1(x)))
+
+
+def fit_step_with_masks(model, optimizer, x, y, masks, loss_fn=bce_logits, routes=None, audit=None):
+    """fit_step (sed.py:134-137) through forward_with_masks (or forward_routed when `routes` are given)"""
     model.train()
     optimizer.zero_grad()
-    out = forward_with_masks(model, x, masks)
+    out = forward_with_masks(model, x, masks) if routes is None else forward_routed(model, x, routes, masks, audit=audit)
     loss = loss_fn(out, y)
     loss.backward()
     optimizer.step()

@@ -29,6 +29,7 @@ class NetCfg(C.Structure):
         ("n_dense", C.c_int), ("D", C.c_int * SED_MAX_DENSE),
         ("bn_eps", C.c_float), ("bn_momentum", C.c_float),
         ("conv_mode", C.c_int),
+        ("flags", C.c_int),
     ]
 
 
@@ -73,6 +74,7 @@ SIGNATURES = {
     "sed_conv1_bwd_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sed_conv1_bwd_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _stream]),
     "sed_conv1_bwd_wgrad_assemble": (_i, [_fp, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _stream]),
+    "sed_conv1_route": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv1_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_conv1_bwd_apply_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sed_conv1_bwd_apply_wgrad": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _fp, _fp, _fp, _stream]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "sed_bn_finalize_from_sums": (_i, [_fp, _i, _d, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _stream]),
     "sed_bn_finalize_eval": (_i, [_fp, _fp, _fp, _fp, _f, _i, _fp, _fp, _stream]),
     "sed_bn_relu_pool_drop_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
+    "sed_bn_relu_pool_route": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_bn_bwd_rows": (_i, [_i, _i, _i]),
     "sed_bn_relu_pool_drop_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_bn_bwd_finalize": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _stream]),
@@ -124,6 +127,7 @@ SIGNATURES = {
     "sed_net_forward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _fp, _stream]),
     "sed_net_sync_region": (_i, [C.POINTER(NetCfg), _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
     "sed_net_workspace_region": (_i, [C.POINTER(NetCfg), _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "sed_net_routing": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _i, _fp, _stream]),
     "sed_net_forward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), _fp, _fp, _fp, _i, _u64, _i, _i, _f, _stream]),
     "sed_net_backward_phases": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _i, _i, _f, _stream]),
     "sed_net_backward": (_i, [C.POINTER(NetCfg), C.POINTER(NetParams), C.POINTER(NetParams), _fp, _fp, _fp, _u64, _fp, _i, _i, _stream, _stream]),

@@ -301,6 +301,55 @@ extern "C" int sed_bn_relu_pool_drop_fwd(const float* y, const float* scale, con
     return 0;
 }
 
+// ── routing decisions of the block (inspection / parity tests): which element of every pooling window the gradient takes ──
+// The same expressions as the forward and backward kernels (z = y*scale + shift, first maximum wins, gate = max > 0), so the
+// codes are exactly the decisions those kernels make.  route [B][Tp][Fp][C]: 0 = ReLU gate closed, 1 + w = window element
+// w = df*pt + dt.  Independent of dropout (the keep-mask multiplies afterwards).
+__global__ __launch_bounds__(256) void bn_relu_pool_route_k(
+    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    unsigned char* __restrict__ route, int B, int T, int F, int C, int pf, int pt) {
+    const int Tp = T / pt, Fp = F / pf, C4 = C >> 2;
+    const size_t n = (size_t)B * Tp * Fp * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int c4 = (int)(i % C4);
+        size_t pos = i / C4;
+        int fp = (int)(pos % Fp);
+        size_t bt = pos / Fp;
+        int tp = (int)(bt % Tp);
+        size_t b = bt / Tp;
+        f32x4 sc = *(const f32x4*)(scale + c4 * 4), sh = *(const f32x4*)(shift + c4 * 4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bidx[4] = {0, 0, 0, 0};
+        int widx = 0;
+        for (int df = 0; df < pf; ++df)
+            for (int dt = 0; dt < pt; ++dt, ++widx) {
+                f32x4 v = *(const f32x4*)(y + (((b * T + tp * pt + dt) * F + fp * pf + df) * (size_t)C) + c4 * 4);
+                f32x4 z = v * sc + sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (z[k] > best[k]) { best[k] = z[k]; bidx[k] = widx; }
+            }
+        uchar4 code;
+        code.x = best[0] > 0.f ? (unsigned char)(1 + bidx[0]) : 0;
+        code.y = best[1] > 0.f ? (unsigned char)(1 + bidx[1]) : 0;
+        code.z = best[2] > 0.f ? (unsigned char)(1 + bidx[2]) : 0;
+        code.w = best[3] > 0.f ? (unsigned char)(1 + bidx[3]) : 0;
+        *(uchar4*)(route + i * 4) = code;
+    }
+}
+
+extern "C" int sed_bn_relu_pool_route(const float* y, const float* scale, const float* shift, unsigned char* route,
+                                      int B, int T, int F, int C, int pf, int pt, void* stream) {
+    SED_REQUIRE(y && scale && shift && route, "bn_relu_pool_route: null pointer");
+    SED_TRY(check_pool("bn_relu_pool_route", B, T, F, C, pf, pt));
+    SED_REQUIRE(pf * pt <= 254, "bn_relu_pool_route: a %dx%d window does not fit the one-byte code", pf, pt);
+    size_t n = (size_t)B * (T / pt) * (F / pf) * (C / 4);
+    int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    bn_relu_pool_route_k<<<grid, 256, 0, as_stream(stream)>>>(y, scale, shift, route, B, T, F, C, pf, pt);
+    SED_LAUNCH_CHECK("bn_relu_pool_route");
+    return 0;
+}
+
 // ───────────────────────── backward ─────────────────────────
 extern "C" int sed_bn_bwd_rows(int B, int T, int pool_t) {
     long r = (long)B * (T / (pool_t > 0 ? pool_t : 1));

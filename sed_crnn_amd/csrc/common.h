@@ -50,9 +50,16 @@ struct SedProfScope {
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
                                  void* stream);
 
-// internal (misc.hip): one wave that idles for `us` microseconds (<= 100) on `stream` — used to let a kernel on another stream,
-// released by the same event, reach the CUs first (see sed_net_backward)
-int sed_internal_stream_delay(int us, void* stream);
+// internal (conv.hip): sed_conv3x3_wgrad_ex whose exact-fp32 MFMA kernels add 1 to *arrive (agent scope) as each workgroup
+// starts; _workgroups: how many that will be (0: this shape's kernel does not announce itself)
+int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                               int B, int Cin, int F, int T, int Cout, int mode, unsigned* arrive, void* stream);
+int sed_internal_conv3x3_wgrad_workgroups(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode);
+
+// internal (misc.hip): a one-wave kernel on `stream` that returns once *counter >= target — i.e. once that many workgroups of a
+// kernel on ANOTHER stream are resident — or after timeout_us (a deadlock guard, not the mechanism).  What is enqueued behind
+// it on `stream` then moves in BESIDE that kernel instead of taking its CUs (see sed_net_backward).
+int sed_internal_stream_gate(const unsigned* counter, unsigned target, int timeout_us, void* stream);
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1423,8 +1423,9 @@ typedef __attribute__((address_space(3))) void* sed_lptr_t;
 template <bool MT>
 __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
-    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles) {
+    int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft, int tblocks, int ntiles, unsigned* __restrict__ arrive) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (arrive && threadIdx.x == 0) (void)__hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "this workgroup is resident" (sed_internal_stream_gate)
     constexpr int NX = WG_NX, ND = WG_ND;
     const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
@@ -1556,7 +1557,8 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
 template <int FT>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, const float* __restrict__ zrow,
-    int B, int Cin, int F, int T, int Cout, int nft, int tblocks, int ntiles) {
+    int B, int Cin, int F, int T, int Cout, int nft, int tblocks, int ntiles, unsigned* __restrict__ arrive) {
+    if (arrive && threadIdx.x == 0) (void)__hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // "this workgroup is resident" (sed_internal_stream_gate)
     constexpr int TT = 2, F2 = FT + 2;
     constexpr int PX = FT + 4;                      // halo row pitch: the second b128 of the k = 1 half reaches column FT + 3
     constexpr int XCI = (TT + 2) * PX + 4;          // floats per input channel
@@ -1927,6 +1929,21 @@ extern "C" int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy,
 
 extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
                                     int B, int Cin, int F, int T, int Cout, int mode, void* stream) {
+    return sed_internal_conv3x3_wgrad(x, x_is_nchw, dy, dw, workspace, B, Cin, F, T, Cout, mode, nullptr, stream);
+}
+
+// workgroups of the exact-fp32 MFMA weight gradient of this shape (they are persistent: one per CU for the kernel's lifetime,
+// and each announces itself on `arrive`); 0 for the shapes / modes whose kernel does not announce
+int sed_internal_conv3x3_wgrad_workgroups(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode) {
+    if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
+    mode &= ~SED_WGRAD_ZERO_ROW_CLEAN;
+    if (mode != 0) return 0;
+    const WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
+    return p.kind == 1 ? p.ngroups * (Cin / 32) * (Cout / 128) : 0;
+}
+
+int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,
+                               int B, int Cin, int F, int T, int Cout, int mode, unsigned* arrive, void* stream) {
     SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
     const bool zero_row_clean = (mode & SED_WGRAD_ZERO_ROW_CLEAN) != 0;      // the caller cleared sed_conv3x3_wgrad_zero_row_bytes()
     mode &= ~SED_WGRAD_ZERO_ROW_CLEAN;
@@ -1961,10 +1978,10 @@ extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* 
         }
         if (p.FT == 40) {
             SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<40>, p.lds));
-            conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
         } else {
             SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<32>, p.lds));
-            conv3x3_mfma_wgrad2_k<32><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad2_k<32><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
         }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
@@ -1972,10 +1989,10 @@ extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* 
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
         if (p.nft == 1) {
             SED_TRY(set_lds(conv3x3_mfma_wgrad_k<false>, p.lds));
-            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad_k<false><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles, arrive);
         } else {
             SED_TRY(set_lds(conv3x3_mfma_wgrad_k<true>, p.lds));
-            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles);
+            conv3x3_mfma_wgrad_k<true><<<grid, 256, p.lds, s>>>(x, dy, slabs, B, Cin, F, T, Cout, p.TT, p.FT, p.nft, p.tblocks, p.ntiles, arrive);
         }
         SED_LAUNCH_CHECK("conv3x3_mfma_wgrad");
         conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);

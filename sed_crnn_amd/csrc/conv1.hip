@@ -87,6 +87,8 @@ __device__ __forceinline__ void c1_stage(float* halo, const float* __restrict__ 
 }
 
 // MODE 0: stats  1: forward  2: backward reduce  3: backward apply + weight gradient
+//      4: routing codes (inspection / parity tests): the decisions of passes 2 and 3 — same search, same expressions — as
+//         one byte per pooled element in `out` ([B][Tp][Fp][C]: 0 = ReLU gate closed, 1 + w = window element w = df*pt + dt)
 // P12: the pool is (1,2): unrolled window, both conv outputs of a window from one halo patch, kept for the apply loop
 template <int CIN, int MODE, bool P12>
 __global__ __launch_bounds__(256) void conv1_fused_k(
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
     if (active && MODE >= 1) {
         sc = *(const f32x4*)(scale + cg * 4);
         sh = *(const f32x4*)(shift + cg * 4);
-        if (MODE >= 2) { mu = *(const f32x4*)(mean + cg * 4); rs = *(const f32x4*)(rstd + cg * 4); }
+        if (MODE >= 2 && MODE != 4) { mu = *(const f32x4*)(mean + cg * 4); rs = *(const f32x4*)(rstd + cg * 4); }
         if (MODE == 3) { sg = *(const f32x4*)(sum_g + cg * 4) * invN; sgx = *(const f32x4*)(sum_gx + cg * 4) * invN; }
     }
     f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};              // stats / (sum g, sum g xhat) / (dbias, sum g xhat again)
@@ -171,10 +173,13 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                     }
                     *(f32x4*)(out + oi) = m;
                 } else {
-                    f32x4 g = *(const f32x4*)(dout + oi);
-                    if (drop_p > 0.f) {
+                    f32x4 g = {0, 0, 0, 0};
+                    if (MODE != 4) {
+                        g = *(const f32x4*)(dout + oi);
+                        if (drop_p > 0.f) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) g[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+                            for (int k = 0; k < 4; ++k) g[k] *= sed_drop_mult(seed, oi + k, drop_p, inv_keep);
+                        }
                     }
                     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, bx = {0, 0, 0, 0};
                     int bidx[4] = {0, 0, 0, 0};
@@ -189,6 +194,15 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
                             for (int k = 0; k < 4; ++k)
                                 if (z[k] > best[k]) { best[k] = z[k]; bx[k] = (v[k] - mu[k]) * rs[k]; bidx[k] = widx; }
                         }
+                    if (MODE == 4) {
+                        uchar4 code;
+                        code.x = best[0] > 0.f ? (unsigned char)(1 + bidx[0]) : 0;
+                        code.y = best[1] > 0.f ? (unsigned char)(1 + bidx[1]) : 0;
+                        code.z = best[2] > 0.f ? (unsigned char)(1 + bidx[2]) : 0;
+                        code.w = best[3] > 0.f ? (unsigned char)(1 + bidx[3]) : 0;
+                        *(uchar4*)(reinterpret_cast<unsigned char*>(out) + oi) = code;
+                        continue;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (!(best[k] > 0.f)) g[k] = 0.f;
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256) void conv1_fused_k(
             }
         }
     }
-    if (MODE == 1) return;
+    if (MODE == 1 || MODE == 4) return;
     // block reduction in fixed slot order, NVC values per round: the apply pass runs beside the conv weight-gradient kernel,
     // which leaves ~38 KB of LDS per CU, so its 1 + 9*CIN values go through a 20 KB buffer in rounds of 5
     constexpr int NV = (MODE == 3) ? 2 + 9 * CIN : 2;       // MODE 3: dbias, 9*CIN weight-gradient taps, sum g*xhat
@@ -748,7 +762,7 @@ static int c1_launch(const float* x, const float* wp, const float* bias, const f
     } while (0)
     if (Cin == 1) { if (p12) C1_LAUNCH(1, true); else C1_LAUNCH(1, false); }
     else if (Cin == 2) { if (p12) C1_LAUNCH(2, true); else C1_LAUNCH(2, false); }
-    else if (MODE == 1 && p12) {           // 3 / 4 input channels: the forward pass only (statistics from the blocked moment
+    else if ((MODE == 1 || MODE == 4) && p12) {           // 3 / 4 input channels: the forward pass only (statistics from the blocked moment
         if (Cin == 3) C1_LAUNCH(3, true);  // kernel, backward through sed_conv3x3_dgrad_bnred + sed_conv1_bwd_wgrad)
         else C1_LAUNCH(4, true);
     } else {
@@ -836,6 +850,18 @@ extern "C" int sed_conv1_bn_relu_pool_drop_fwd(const float* x, const float* wp, 
     SED_REQUIRE(!argmax_bits || (pf == 1 && pt == 2), "conv1_fwd: arg-max bits exist for the (1,2) pool only");
     SED_TRY(c1_launch<1>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, out, reinterpret_cast<float*>(argmax_bits), B, Cin, F, T, C, pf, pt, drop_p, seed, seed_dev, s));
     SED_LAUNCH_CHECK("conv1_fwd");
+    return 0;
+}
+
+extern "C" int sed_conv1_route(const float* x, const float* wp, const float* bias, const float* scale, const float* shift,
+                               unsigned char* route, int B, int Cin, int F, int T, int C, int pf, int pt, void* stream) {
+    SED_REQUIRE(x && wp && scale && shift && route, "conv1_route: null pointer");
+    SED_REQUIRE(c1_shape_ok(Cin, F, T, C, pf, pt, (pf == 1 && pt == 2) ? 4 : 2), "conv1_route: shape Cin=%d F=%d T=%d C=%d pool=(%d,%d) is not "
+                "supported by the fused first block", Cin, F, T, C, pf, pt);
+    SED_REQUIRE(pf * pt <= 254, "conv1_route: a %dx%d window does not fit the one-byte code", pf, pt);
+    SED_TRY(c1_launch<4>(x, wp, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<float*>(route), nullptr,
+                         B, Cin, F, T, C, pf, pt, 0.f, 0, nullptr, as_stream(stream)));
+    SED_LAUNCH_CHECK("conv1_route");
     return 0;
 }
 

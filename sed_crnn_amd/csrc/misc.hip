@@ -172,15 +172,23 @@ extern "C" int sed_adam_step(float* p, const float* g, float* m, float* v, long 
 // captured hipGraph of the step draws fresh dropout masks and uses the right Adam bias correction on every replay
 __global__ void step_advance_k(uint64_t* st) { st[0] += 1; st[1] += 1; }
 
-__global__ void stream_delay_k(unsigned ticks) {          // s_memrealtime runs at 100 MHz
+// One lane polls an arrival counter that the workgroups of a kernel on another stream bump as they start (agent-scope atomic
+// adds, conv.hip; an sc1 load here: the per-XCD L2s are not coherent).  Every path leaves the loop: the count is reached, or
+// the s_memrealtime (100 MHz) deadline passes.
+__global__ void stream_gate_k(const unsigned* __restrict__ counter, unsigned target, unsigned timeout_ticks) {
+    if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
 }
-int sed_internal_stream_delay(int us, void* stream) {
-    if (us <= 0) return 0;
-    if (us > 100) us = 100;
-    stream_delay_k<<<1, 64, 0, as_stream(stream)>>>((unsigned)us * 100u);
-    SED_LAUNCH_CHECK("stream_delay");
+int sed_internal_stream_gate(const unsigned* counter, unsigned target, int timeout_us, void* stream) {
+    if (!counter || target == 0) return 0;
+    if (timeout_us < 1) timeout_us = 1;
+    if (timeout_us > 5000) timeout_us = 5000;
+    stream_gate_k<<<1, 64, 0, as_stream(stream)>>>(counter, target, (unsigned)timeout_us * 100u);
+    SED_LAUNCH_CHECK("stream_gate");
     return 0;
 }
 

@@ -28,6 +28,8 @@ struct Layout {
     size_t act[SED_MAX_DENSE];
     // backward only
     size_t wgrad_zrow;       // floats at the start of wgrad_ws / wgrad_ws_aux that the backward keeps zero (sed_conv3x3_wgrad_zero_row_bytes)
+    size_t wg_arrive;        // one granule right in front of wgrad_ws (cleared by the same memset as its zero row): word 0 = arrival
+                             // counter of the first deferred weight gradient's workgroups (sed_internal_stream_gate)
     size_t bn_part, sum_g, sum_gx, dbias_part, dconv[SED_MAX_CONV], gradA, wgrad_ws, wgrad_ws_aux, c1_ws, dgi[SED_MAX_GRU], dgh[SED_MAX_GRU], gru_bws, dgout[SED_MAX_GRU];
     size_t dact[SED_MAX_DENSE], lin_ws, gemm_ws, gemm_ws_aux;
     size_t total;     // floats
@@ -45,6 +47,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     SED_REQUIRE(c->n_gru >= 1 && c->n_gru <= SED_MAX_GRU, "net: n_gru=%d out of range", c->n_gru);
     SED_REQUIRE(c->n_dense >= 1 && c->n_dense <= SED_MAX_DENSE, "net: n_dense=%d out of range", c->n_dense);
     SED_REQUIRE(c->conv_mode == 0 || c->conv_mode == 1, "net: conv_mode=%d (0 = exact fp32, 1 = bf16x3 experiment)", c->conv_mode);
+    SED_REQUIRE((c->flags & ~(SED_NET_AUX_FIRST | SED_NET_NO_GATE)) == 0, "net: unknown flags 0x%x", c->flags);
     memset(L, 0, sizeof(*L));
     L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
     Carver cv;
@@ -163,7 +166,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
             L->dconv[l] = L->cv[l].fused ? 0 : cv.take((size_t)c->B * L->cv[l].T * L->cv[l].F * L->cv[l].C);
         size_t ga = max_pool > M * (size_t)L->feat ? max_pool : M * (size_t)L->feat;
         L->gradA = cv.take(ga);
-        L->wgrad_ws = cv.take(max_wgrad + 64);
+        L->wg_arrive = cv.take(64);
+        L->wgrad_ws = cv.take(max_wgrad + 64);               // (contiguous with wg_arrive: the carver hands out whole granules)
         L->wgrad_ws_aux = cv.take(max_wgrad + 64);
         L->c1_ws = cv.take(c1_ws);
         // gate gradients per GRU layer: the weight-gradient GEMMs of layer i (auxiliary stream) still read them while the
@@ -375,10 +379,34 @@ extern "C" int sed_net_workspace_region(const sed_net_cfg* c, int training, cons
             ok = true;
         } else if (is("bn_sums_bwd")) { off = L.sum_g; n = 2 * (size_t)L.cv[0].C; ok = true; }
     }
+    if (!ok && training && (index == 0 || index == 1) && is("wgrad_zero_row") && L.wgrad_zrow > 0) {
+        off = index ? L.wgrad_ws_aux : L.wgrad_ws; n = L.wgrad_zrow; ok = true;      // the rows the backward keeps zero (main / auxiliary scratch)
+    }
     SED_REQUIRE(ok, "net_workspace_region: no region '%s'[%d] in this plan (training=%d)", name, index, training);
     *offset_bytes = off * sizeof(float);
     *n_floats = n;
     return 0;
+}
+
+// The ReLU-gate / pooling arg-max decisions of conv block `block` in the LAST training forward that ran on this workspace, as
+// the backward kernels make them (sed_bn_relu_pool_route on the stored conv output, sed_conv1_route for a recomputed first
+// block).  route: caller-owned [B][T_l/pt][F_l/pf][C] bytes.  For parity tests: an oracle that routes its gradients with
+// THESE decisions differs from the plan by rounding only, however many near-ties the batch holds.
+extern "C" int sed_net_routing(const sed_net_cfg* c, const sed_net_params* p, const float* x, const void* workspace, int block,
+                               unsigned char* route, void* stream) {
+    SED_REQUIRE(p && x && workspace && route, "net_routing: null pointer");
+    Layout L;
+    SED_TRY(build_layout(c, 1, &L));
+    SED_REQUIRE(block >= 0 && block < L.n_conv, "net_routing: block %d out of range", block);
+    const float* ws = (const float*)workspace;
+    const ConvL& q = L.cv[block];
+    if (q.fused) {
+        SED_REQUIRE(p->conv_b[block], "net_routing: missing parameters of conv block %d", block);
+        return sed_conv1_route(x, ws + L.wp_f[block], p->conv_b[block], ws + L.scale[block], ws + L.shift[block], route,
+                               c->B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, stream);
+    }
+    return sed_bn_relu_pool_route(ws + L.conv_out[block], ws + L.scale[block], ws + L.shift[block], route,
+                                  c->B, q.T, q.F, q.C, q.pf, q.pt, stream);
 }
 
 // BatchNorm/ReLU/pool/dropout backward of block l on stream `st` (for the fused first block: everything of block 0).
@@ -466,8 +494,9 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     static thread_local hipEvent_t ev_all[kMaxDev][2][SED_MAX_CONV] = {};
     // [i]: recurrence of GRU layer i done (main); [SED_MAX_GRU]: the GRU weight gradients of the aux stream done;
     // [SED_MAX_GRU + 1]: data gradient of the top conv block issued (main); [SED_MAX_GRU + 2]: its weight gradient done (aux);
-    // [SED_MAX_GRU + 3]: the zero rows of the weight-gradient workspaces cleared (aux)
-    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 4] = {};
+    // [SED_MAX_GRU + 3]: the zero rows of the weight-gradient workspaces cleared (aux); [SED_MAX_GRU + 4]: the fork of the
+    // auxiliary stream at the top of the call (main)
+    static thread_local hipEvent_t ev_gru_all[kMaxDev][SED_MAX_GRU + 5] = {};
     hipStream_t s_main = as_stream(stream), s_aux = as_stream(aux_stream);
     hipEvent_t* ev_dg = nullptr;
     hipEvent_t* ev_bn = nullptr;
@@ -481,7 +510,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         ev_dg = ev_all[dev][0];
         ev_bn = ev_all[dev][1];
         ev_gru = ev_gru_all[dev];
-        for (int i = 0; i < SED_MAX_GRU + 4; ++i)
+        for (int i = 0; i < SED_MAX_GRU + 5; ++i)
             if (!ev_gru[i] && hipEventCreateWithFlags(&ev_gru[i], hipEventDisableTiming) != hipSuccess) {
                 sed_set_error("net_backward: hipEventCreate failed");
                 return SED_EINVAL;
@@ -505,15 +534,23 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     const int B = c->B, M = L.M;
 
     // The exact-fp32 weight-gradient kernel reads out-of-image rows from a zero-filled row at the start of its workspace.  Nothing
-    // writes those bytes, so this call clears them once, on the auxiliary stream where it costs the critical chain nothing, and
-    // passes SED_WGRAD_ZERO_ROW_CLEAN: the memset node in front of each weight gradient is gone (two per step, one of them on
-    // the chain; the top block's weight gradient also starts 6 us earlier and now gets its CUs before the BatchNorm apply pass
-    // below it — it shares the machine with that HBM-bound pass instead of with the MFMA data gradient: step -15 us).
+    // writes those bytes, so the backward clears them once — in the call that holds stage 0, on the auxiliary stream, where it
+    // costs the critical chain nothing — and passes SED_WGRAD_ZERO_ROW_CLEAN: the memset node in front of each weight gradient
+    // is gone (two per step, one of them on the chain).  The same memset clears the arrival counter in front of wgrad_ws.
+    // The auxiliary stream is FORKED from the main stream first (event record + wait): under hipGraph capture that is what
+    // makes it part of the capture, so the memsets are graph nodes and every replay clears the rows again (round-3 advisor:
+    // issued on the un-forked stream they ran once, outside the graph, and every replay trusted bytes nobody re-cleared).
     const int wg_clean = (L.wgrad_zrow > 0 && s_aux) ? SED_WGRAD_ZERO_ROW_CLEAN : 0;
-    if (wg_clean) {
-        (void)hipMemsetAsync(ws + L.wgrad_ws, 0, L.wgrad_zrow * sizeof(float), s_aux);
-        (void)hipMemsetAsync(ws + L.wgrad_ws_aux, 0, L.wgrad_zrow * sizeof(float), s_aux);
-        (void)hipEventRecord(ev_gru[SED_MAX_GRU + 3], s_aux);
+    if (s_aux && stage_begin == 0 && L.n_conv > 1) {
+        hipError_t e = hipEventRecord(ev_gru[SED_MAX_GRU + 4], s_main);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s_aux, ev_gru[SED_MAX_GRU + 4], 0);
+        if (e == hipSuccess) e = hipMemsetAsync(ws + L.wg_arrive, 0, (64 + L.wgrad_zrow) * sizeof(float), s_aux);
+        if (e == hipSuccess && L.wgrad_zrow > 0) e = hipMemsetAsync(ws + L.wgrad_ws_aux, 0, L.wgrad_zrow * sizeof(float), s_aux);
+        if (e == hipSuccess) e = hipEventRecord(ev_gru[SED_MAX_GRU + 3], s_aux);
+        if (e != hipSuccess) {          // fail loudly: a weight gradient that trusts an un-cleared row would be silently wrong
+            sed_set_error("net_backward: clearing the weight-gradient zero rows failed: %s", hipGetErrorString(e));
+            return (int)e;
+        }
     }
 
     if (stage_begin == 0) {
@@ -632,7 +669,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         // (the zero rows were cleared on the auxiliary stream at the top of this call: ordered here, far from the launches
         // that read them — a wait right in front of the last weight gradient let the first block's pass on the auxiliary
         // stream reach the CUs first, see below)
-        if (wg_clean) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU + 3], 0);
+        if (s_aux) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU + 3], 0);
         // data gradient = the same convolution with flipped, transposed taps (+ the BatchNorm-backward sums of the block below)
         SED_TRY(dgrad(L, c, p, x, ws, l, stream));
         if (l > 1) {
@@ -647,6 +684,34 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             SED_TRY(bn_passes(l - 1, stream));
             continue;
         }
+        // the deferred MFMA weight gradients, main stream (the top block's runs on the auxiliary stream since its own stage)
+        int first_wg = 0;
+        for (int k = top; k >= 1 && !first_wg; --k)
+            if (!(k == top && top_wgrad_on_aux)) first_wg = k;
+        unsigned* arrive = nullptr;
+        unsigned gate_target = 0;
+        if (s_aux && first_wg && !(c->flags & SED_NET_NO_GATE)) {
+            const ConvL& w = L.cv[first_wg];
+            int n = sed_internal_conv3x3_wgrad_workgroups(B, w.Cin, w.F, w.T, w.C, w.nchw, c->conv_mode);
+            static thread_local int n_cu[kMaxDev] = {};
+            int dev = 0;
+            if (n > 0 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) {
+                if (!n_cu[dev] && hipDeviceGetAttribute(&n_cu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu[dev] = 0;
+                if (n_cu[dev] > 0) {        // the kernel holds one workgroup per CU: at most that many are resident at once
+                    gate_target = (unsigned)(n < n_cu[dev] ? n : n_cu[dev]);
+                    arrive = (unsigned*)(ws + L.wg_arrive);
+                }
+            }
+        }
+        auto main_wgrads = [&]() -> int {
+            for (int k = top; k >= 1; --k) {
+                if (k == top && top_wgrad_on_aux) continue;
+                const ConvL& w = L.cv[k];
+                SED_TRY(sed_internal_conv3x3_wgrad(ws + L.pooled[k - 1], w.nchw, ws + L.dconv[k], g->conv_w[k], ws + L.wgrad_ws, B, w.Cin, w.F, w.T, w.C,
+                                                   c->conv_mode | wg_clean, k == first_wg ? arrive : nullptr, stream));
+            }
+            return 0;
+        };
         if (s_aux) {
             // block 0's sums came out of the data gradient just issued: finalising them is one tiny launch (16 workgroups, 10 us
             // alone) that took 0.1-0.33 ms when it started the auxiliary chain BESIDE the MFMA weight gradient; on the main
@@ -654,23 +719,33 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
             const bool fin_on_main = L.cv[0].red_rows > 0;
             if (fin_on_main) SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, 1, 1.f, stream));
             (void)hipEventRecord(ev_dg[0], s_main);
-            (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
-            // The first block's passes and the weight gradient issued below on the main stream are released by the same event;
-            // the persistent MFMA kernel must get the CUs FIRST (the passes then move in beside it): the other way round its
-            // workgroups wait for the passes' workgroups to retire — config 5: 8.6 -> 16.8 ms for that kernel, 62 -> 69 ms per
-            // step, decided by a microsecond (it used to be decided by the memset node that is gone now).  A 20 us idle wave
-            // in front of the auxiliary chain makes it deterministic; that chain has a millisecond of slack.
-            SED_TRY(sed_internal_stream_delay(20, aux_stream));
-            SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, fin_on_main ? 2 : 3, 1.f, aux_stream));
-            if (wg0_with_bn) SED_TRY(wgrad_on(0, aux_stream));
-            (void)hipEventRecord(ev_bn[0], s_aux);
+            // The first block's passes (auxiliary stream) and the weight gradient (main stream) are released by the same event.
+            // The persistent MFMA kernel must hold its CUs FIRST — the passes then move in beside it; the other way round its
+            // one-per-CU workgroups (132 KB of LDS, 328 registers per lane) find no CU until the passes' grid is exhausted
+            // (config 5: 8.6 -> 16.8 ms for that kernel, 62 -> 69 ms per step).  Round 3 ordered the two with a 20 us sleep;
+            // now it is a dependency: the kernel's workgroups count themselves in (`arrive`), and a one-wave gate at the head of
+            // the auxiliary chain returns when as many as can be resident are (sed_internal_stream_gate; its timeout only
+            // guards against a weight gradient that never starts).  The host enqueues the main-stream kernel first, so under
+            // load the gate is never enqueued before the kernel it waits for; SED_NET_AUX_FIRST forces the other order (tests).
+            auto aux_chain = [&]() -> int {
+                (void)hipStreamWaitEvent(s_aux, ev_dg[0], 0);
+                SED_TRY(sed_internal_stream_gate(arrive, gate_target, 2000, aux_stream));
+                SED_TRY(bn_backward(L, c, p, g, x, ws, seed, seed_dev, 0, fin_on_main ? 2 : 3, 1.f, aux_stream));
+                if (wg0_with_bn) SED_TRY(wgrad_on(0, aux_stream));
+                (void)hipEventRecord(ev_bn[0], s_aux);
+                return 0;
+            };
+            if (c->flags & SED_NET_AUX_FIRST) {
+                SED_TRY(aux_chain());
+                SED_TRY(main_wgrads());
+            } else {
+                SED_TRY(main_wgrads());
+                SED_TRY(aux_chain());
+            }
         } else {
             SED_TRY(bn_passes(0, stream));
             if (wg0_with_bn) SED_TRY(wgrad_on(0, stream));
-        }
-        for (int k = top; k >= 1; --k) {
-            if (k == top && top_wgrad_on_aux) continue;
-            SED_TRY(wgrad(k));
+            SED_TRY(main_wgrads());
         }
         if (top_wgrad_on_aux) (void)hipStreamWaitEvent(s_main, ev_gru[SED_MAX_GRU + 2], 0);
     }

@@ -336,6 +336,7 @@ class HipCRNN(nn.Module):
             c.D[j] = d
         c.bn_eps, c.bn_momentum = self.bn_eps, self.bn_momentum
         c.conv_mode = int(getattr(self, "conv_mode", 0))
+        c.flags = int(getattr(self, "plan_flags", 0))          # SED_NET_* (tests / A-B measurements of the backward schedule)
         return c
 
     def set_conv_precision(self, name="f32"):
@@ -446,7 +447,7 @@ class HipCRNN(nn.Module):
     def workspace_view(self, name, index=0):
         """A view of an intermediate of the LAST training forward / backward inside the plan's workspace
         (``sed_net_workspace_region``: "conv_out", "pooled", "mean", "rstd", "scale", "shift", "dconv", "gi", "gru_out",
-        "dgru_out", "grad_act", "bn_sums_bwd").  Flat fp32; valid until the next forward of that shape."""
+        "dgru_out", "grad_act", "bn_sums_bwd", "wgrad_zero_row").  Flat fp32; valid until the next forward of that shape."""
         if self._last is None:
             raise RuntimeError("sed_crnn_amd: no training forward to look into")
         cfg, ws, _ = self._last
@@ -454,6 +455,24 @@ class HipCRNN(nn.Module):
         check(lib().sed_net_workspace_region(C.byref(cfg), 1, name.encode(), int(index), C.byref(off), C.byref(n)),
               "sed_net_workspace_region")
         return ws[off.value // 4: off.value // 4 + n.value]
+
+    def routing(self, block):
+        """The ReLU-gate / pooling arg-max decisions of conv block ``block`` in the LAST training forward, exactly as the
+        backward kernels take them (``sed_net_routing``): uint8 [B, T_l/pt, F_l/pf, C], 0 = gate closed, 1 + w = the gradient
+        goes to window element w = df*pt + dt.  Inspection / parity tests (oracle.crnn_ref.forward_routed).  Call it BEFORE the
+        optimiser step: a recomputed first block re-reads its (live) conv bias."""
+        if self._last is None:
+            raise RuntimeError("sed_crnn_amd: no training forward to look into")
+        cfg, ws, x = self._last
+        P, _ = self._param_structs()
+        T, F = cfg.T, cfg.F
+        for l in range(block):
+            T, F = T // self.pools[l][1], F // self.pools[l][0]
+        pf, pt = self.pools[block]
+        route = torch.empty(cfg.B, T // pt, F // pf, self.conv_channels[block], device=x.device, dtype=torch.uint8)
+        check(lib().sed_net_routing(C.byref(cfg), C.byref(P), _lib.ptr(x), _lib.ptr(ws), int(block), _lib.ptr(route),
+                                    _lib.stream_ptr()), "sed_net_routing")
+        return route
 
     # ── raw plan calls (also used by the fused trainer) ──
     def _run_forward(self, x, training, step_state=None):

@@ -390,3 +390,41 @@ def test_fused_adam_leaves_frozen_parameters_alone(sed):
     # step 1 is identical for every trainable parameter; in step 2 the frozen conv1 changes the forward, so only check movement
     for k in ("gru.weight_ih_l0", "fc.weight", "convs.2.weight"):
         assert not torch.equal(a1[k], b1[k])
+
+
+def test_captured_step_clears_the_weight_gradient_zero_rows_on_every_replay(sed):
+    """round-3 advisor (medium): the exact-fp32 weight gradient reads out-of-image rows from a zero row at the head of its
+    scratch that the backward clears once per call.  Those clears used to be issued on the auxiliary stream BEFORE it was
+    forked from the capturing stream, i.e. outside the hipGraph: every replay trusted bytes that only the warm-up had cleared.
+    Now the fork comes first and the memsets are graph nodes: poison the rows between two replays of a captured step and the
+    conv weight gradients must not move (lr = 0, dropout 0: every replay computes the same step)."""
+    from sed_crnn_amd.trainer import FusedTrainStep
+    from oracle import crnn_ref
+    torch.manual_seed(11)
+    m = sed.TimePooledCRNN(conv_channels=128, dropout=0.0, gru_hidden=16).cuda()
+    x, y = crnn_ref.synthetic_batch(4, 1, 40, 64, 8, seed=3)
+    x, y = x.cuda(), y.cuda()
+    st = FusedTrainStep(m, lr=0.0, graph=True)
+    for _ in range(3):                                   # eager warm-up, capture + first replay, second replay
+        st.step(x, y)
+    torch.cuda.synchronize()
+    g_ref = m.flat_grads().clone()
+    assert bool(torch.isfinite(g_ref).all()) and float(g_ref.abs().max()) > 0
+    rows = [m.workspace_view("wgrad_zero_row", i) for i in (0, 1)]
+    assert all(r.numel() > 0 for r in rows)
+    for r in rows:
+        r.fill_(float("nan"))                            # what a stray write (or a failed clear) would leave behind
+    st.step(x, y)
+    torch.cuda.synchronize()
+    assert all(bool((r == 0).all()) for r in rows), "the replay did not clear the zero rows"
+    assert torch.equal(m.flat_grads(), g_ref), "conv weight gradients changed after the zero rows were poisoned"
+    # the eager path clears them per call too
+    m2 = sed.TimePooledCRNN(conv_channels=128, dropout=0.0, gru_hidden=16).cuda()
+    m2.load_state_dict(m.state_dict())
+    st2 = FusedTrainStep(m2, lr=0.0)
+    st2.step(x, y)
+    for i in (0, 1):
+        m2.workspace_view("wgrad_zero_row", i).fill_(float("nan"))
+    st2.step(x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(m2.flat_grads(), g_ref)

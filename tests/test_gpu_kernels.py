@@ -420,6 +420,80 @@ def test_dropout_mask_statistics_and_backward_consistency(ops, tcf):
     close(routed, mask.float() * 2.0, atol=1e-6)
 
 
+@pytest.mark.parametrize("pf,pt,Fm,T", [(1, 2, 40, 16), (5, 1, 40, 8), (2, 2, 13, 9), (3, 2, 41, 10), (1, 4, 8, 12), (1, 1, 6, 5)])
+def test_routing_codes_are_the_decisions_the_backward_kernels_act_on(ops, pf, pt, Fm, T):
+    """sed_bn_relu_pool_route (what model.routing() returns for a stored block and the parity tests inject into the oracle):
+    the codes must be (a) the decisions of the APPLY pass — with the statistics terms forced to 0 its output is non-zero
+    exactly on the coded element of every open window — and (b) what torch's relu + max_pool2d decide on the same z wherever
+    z is not within rounding of a tie.  Ragged mel / time tails (floor pooling), mel pooling, window order (f, t)."""
+    from sed_crnn_amd._lib import lib, ptr, stream_ptr, check
+    from oracle import crnn_ref
+    B, Cc = 3, 16
+    gen = torch.Generator().manual_seed(pf * 100 + pt * 10 + T)
+    y = torch.randn(B, T, Fm, Cc, generator=gen)
+    y[0, 0, 0, :4] = 0.0                                                   # exact ties inside a window: the first element wins
+    scale, shift = torch.rand(Cc, generator=gen) + 0.5, torch.randn(Cc, generator=gen) * 0.3
+    scale[3] = -scale[3]                                                   # a negative gamma flips the arg-max
+    yg, sc, sh = g(y), g(scale), g(shift)
+    Tp, Fp = T // pt, Fm // pf
+    route = torch.empty(B, Tp, Fp, Cc, dtype=torch.uint8, device="cuda")
+    check(lib().sed_bn_relu_pool_route(ptr(yg), ptr(sc), ptr(sh), ptr(route), B, T, Fm, Cc, pf, pt, stream_ptr()))
+    # (a) the apply pass of the backward with sum_g = sum_gx = 0 and dout = 1: dy = scale on the routed element, 0 elsewhere
+    dout = torch.ones(B, Tp, Fp, Cc, device="cuda")
+    dy = torch.empty_like(yg)
+    zero, one = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    dbp = torch.empty(lib().sed_bn_bwd_rows(B, T, pt), Cc, device="cuda")
+    check(lib().sed_bn_relu_pool_drop_bwd_apply(ptr(yg), ptr(dout), ptr(sc), ptr(sh), ptr(zero), ptr(one), ptr(zero), ptr(zero),
+                                                ptr(dy), ptr(dbp), B, T, Fm, Cc, pf, pt, 0, 0.0, 0, None, stream_ptr()))
+    R = crnn_ref.route_mask(route.cpu(), pf, pt, Fm, T)                    # [B,C,F,T]
+    taken = (dy.cpu() != 0).permute(0, 3, 2, 1)
+    assert torch.equal(taken, R.bool()), "route codes differ from where the apply pass sends the gradient"
+    # (b) against torch on z = y*scale + shift (float64: no rounding of its own)
+    z = (y.double() * scale.double() + shift.double()).permute(0, 3, 2, 1)  # [B,C,F,T]
+    n_gate, n_arg, margin = crnn_ref.audit_routes(z, route.cpu(), pf, pt, tol=1e-6)
+    assert n_gate == 0 and margin <= 1e-6
+    pooled_t = F.max_pool2d(torch.relu(z), (pf, pt))
+    pooled_r = crnn_ref.routed_relu_pool(z, R.double(), pf, pt)
+    close(pooled_r, pooled_t, atol=1e-6)
+    # the forward kernel's output is the routed value too
+    out = ops.bn_relu_pool_drop_fwd(yg, sc, sh, pf, pt)
+    close(out.permute(0, 3, 2, 1), pooled_t, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,pf,pt", [(1, 1, 2), (2, 1, 2), (4, 1, 2), (1, 5, 1), (2, 2, 2)])
+def test_routing_codes_of_the_recomputed_first_block(ops, cin, pf, pt):
+    """sed_conv1_route: the decisions of the recomputed block's own passes — equal to the arg-max bits + (pooled > 0) that its
+    (1,2)-pool backward reads, and to relu + max_pool2d on a float64 conv + BatchNorm away from ties"""
+    from sed_crnn_amd._lib import lib, ptr, stream_ptr, check
+    from oracle import crnn_ref
+    B, Fm, T, Cc = 2, 20, 16, 32
+    gen = torch.Generator().manual_seed(cin * 10 + pf + pt)
+    x = torch.randn(B, cin, Fm, T, generator=gen)
+    w = torch.randn(Cc, cin, 3, 3, generator=gen) * 0.3
+    bias, gamma, beta = torch.randn(Cc, generator=gen) * 0.1, torch.rand(Cc, generator=gen) + 0.5, torch.randn(Cc, generator=gen) * 0.2
+    xg, bg = g(x), g(bias)
+    wf, _ = ops.conv3x3_pack(g(w))
+    conv = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    mean, var = conv.mean((0, 2, 3)), conv.var((0, 2, 3), unbiased=False)
+    scale = (gamma.double() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double() - mean * scale.double()).float()
+    sc, sh = g(scale), g(shift)
+    Tp, Fp = T // pt, Fm // pf
+    route = torch.empty(B, Tp, Fp, Cc, dtype=torch.uint8, device="cuda")
+    check(lib().sed_conv1_route(ptr(xg), ptr(wf), ptr(bg), ptr(sc), ptr(sh), ptr(route), B, cin, Fm, T, Cc, pf, pt, stream_ptr()))
+    z = conv * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    n_gate, n_arg, margin = crnn_ref.audit_routes(z, route.cpu(), pf, pt, tol=2e-5)
+    assert n_gate + n_arg <= 2, (n_gate, n_arg)                             # only genuine ties may differ
+    if (pf, pt) == (1, 2):
+        out = torch.empty(B, Tp, Fp, Cc, device="cuda")
+        bits = torch.empty(out.numel() // 4, dtype=torch.uint8, device="cuda")
+        check(lib().sed_conv1_bn_relu_pool_drop_fwd(ptr(xg), ptr(wf), ptr(bg), ptr(sc), ptr(sh), ptr(out), B, cin, Fm, T, Cc, pf, pt,
+                                                    0.0, 0, None, ptr(bits), stream_ptr()))
+        sel = torch.stack([(bits >> k) & 1 for k in range(4)], -1).reshape(B, Tp, Fp, Cc)      # bit k of the quad's byte
+        want = torch.where(out > 0, sel + 1, torch.zeros_like(sel))
+        assert torch.equal(route, want.to(torch.uint8))
+
+
 GEMM_CASES = [(64, 64, 64), (130, 70, 50), (4096, 96, 320), (256, 384, 5120), (384, 640, 512), (33, 17, 9), (512, 768, 1024)]
 
 

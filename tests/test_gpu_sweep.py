@@ -39,23 +39,25 @@ def _cmp(a, b, atol, rtol=0.0, msg=""):
     assert bool((err <= bound).all()), (msg, float(err.max()), float(b.abs().max()))
 
 
-def _deepest_flip_prone_block(bn_out, pools, margin=5e-6):
-    """ReLU and max-pool are discontinuous in their gradient routing: where a BatchNorm output lies within rounding
-    distance of 0, or the two largest values of a live pooling window within rounding distance of each other, two correct
-    fp32 implementations can route the gradient differently (torch fp32 against torch fp64 does: one flipped gate moves a
-    conv weight gradient by ~1 % of its largest entry at these small sizes).  Returns the deepest conv block holding such
-    an element (-1: none): the gradients of that block and of every block before it get the looser bound."""
-    deepest = -1
-    for l, (z, p) in enumerate(zip(bn_out, pools)):
-        near = int((z.abs() < margin).sum())
-        if p > 1:
-            Tw = z.shape[-1] // p * p
-            w = z[..., :Tw].reshape(*z.shape[:-1], Tw // p, p)
-            top = w.topk(2, dim=-1).values
-            near += int((((top[..., 0] - top[..., 1]) < margin) & (top[..., 0] > -margin)).sum())
-        if near:
-            deepest = l
-    return deepest
+def hip_routes(m):
+    """ReLU and max-pool are discontinuous in their gradient routing: where a BatchNorm output lies within rounding distance
+    of 0, or the two largest values of a pooling window within rounding distance of each other, two correct fp32
+    implementations can route the gradient differently (torch fp32 against torch fp64 does: one flipped gate moves a conv
+    weight gradient by ~1 % of its largest entry at these small sizes).  Rounds 2-3 widened the gradient bound to 5 % of the
+    largest entry for every block at or below a near-tie; now the plan's own decisions (``model.routing(l)``, the codes its
+    backward kernels act on) are injected into the oracle (oracle.crnn_ref.forward_routed / routed_relu_pool, after
+    audit_routes has checked that each differing decision IS a tie), both sides compute the same piecewise-linear function,
+    and every gradient keeps the tight bound."""
+    return [m.routing(l).cpu() for l in range(len(m.conv_channels))]
+
+
+ROUTED = {"cases": 0, "with_differing_decisions": 0}
+
+
+def note_audit(audit):
+    """count the cases in which the injected decisions differed from the oracle's own at all (printed by the last sweep test)"""
+    ROUTED["cases"] += 1
+    ROUTED["with_differing_decisions"] += int(any(g + a for g, a, _ in audit))
 
 
 @pytest.mark.parametrize("seed", list(range(48)))
@@ -74,30 +76,23 @@ def test_random_shape_vs_oracle(sed, seed):
         x = x * 3.0
     m.load_state_dict(ref.state_dict())
     m.cuda()
-    ref.train()
-    bn_out = []
-    hooks = [bn.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach())) for bn in ref.bns]
-    out_r = ref(x)
-    for h in hooks:
-        h.remove()
-    flip = _deepest_flip_prone_block(bn_out, c["pools"])
-    assert out_r.shape == (c["B"], c["Tp"], c["K"]), (c, out_r.shape)
-    lf = crnn_ref.bce_logits if c["loss"] == "bce" else crnn_ref.focal_bce
-    lr_ = lf(out_r, y)
-    lr_.backward()
     m.train()
     out = m(x.cuda())
     crit = sed.BCEWithLogitsLoss() if c["loss"] == "bce" else sed.FocalBCELoss()
     lh = crit(out, y.cuda())
     lh.backward()
+    ref.train()
+    audit = []
+    out_r = crnn_ref.forward_routed(ref, x, hip_routes(m), audit=audit)        # the plan's gate / arg-max decisions, audited
+    note_audit(audit)
+    assert out_r.shape == (c["B"], c["Tp"], c["K"]), (c, out_r.shape)
+    lf = crnn_ref.bce_logits if c["loss"] == "bce" else crnn_ref.focal_bce
+    lr_ = lf(out_r, y)
+    lr_.backward()
     _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"train probabilities {c}")
     assert abs(lh.item() - lr_.item()) < 1e-4, c
     rg = dict(ref.named_parameters())
-    for k, p in m.named_parameters():
-        g = rg[k].grad
-        block = int(k.split(".")[1]) if k.startswith(("convs.", "bns.")) else 10 ** 6
-        loose = 5e-2 * float(g.abs().max()) if block <= flip else 0.0          # see _deepest_flip_prone_block
-        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()) + loose, rtol=1e-2, msg=f"{k} {c} flip-prone<= {flip}")
+    _grads_vs(m, lambda k: rg[k].grad, str(c))
     ref.eval()
     m.eval()
     with torch.no_grad():
@@ -111,14 +106,11 @@ def test_random_shape_vs_oracle(sed, seed):
             assert int(sd[k]) == int(rsd[k]) == 1
 
 
-def _grads_vs(m, want_of, flip, msg):
+def _grads_vs(m, want_of, msg):
+    """every gradient, one bound: |d| <= 1e-4 + 1e-4 max|g| + 1e-2 |g| (no widening for near-ties: the routing is injected)"""
     for k, p in m.named_parameters():
         g = want_of(k)
-        block = int(k.split(".")[1]) if k.split(".")[0] in ("convs", "bns") else 10 ** 6
-        if k.startswith("conv_stack."):
-            block = int(k.split(".")[1]) // 4
-        loose = 5e-2 * float(g.abs().max()) if block <= flip else 0.0
-        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()) + loose, rtol=1e-2, msg=f"{k} {msg} flip-prone<= {flip}")
+        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()), rtol=1e-2, msg=f"{k} {msg}")
 
 
 @pytest.mark.parametrize("seed", list(range(100, 116)))
@@ -145,24 +137,20 @@ def test_random_lightning_variant_vs_oracle(sed, seed):
         x = x * 3.0
     m.load_state_dict(ref.state_dict())
     m.cuda()
-    ref.train()
-    bn_out = []
-    hooks = [mod.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach()))
-             for mod in ref.conv_stack if isinstance(mod, torch.nn.BatchNorm2d)]
-    out_r = ref(x)
-    for h in hooks:
-        h.remove()
-    flip = _deepest_flip_prone_block(bn_out, pools)
-    lr_ = crnn_ref.focal_bce(out_r, y)
-    lr_.backward()
     m.train()
     out = m(x.cuda())
     lh = sed.FocalBCELoss()(out, y.cuda())
     lh.backward()
+    ref.train()
+    audit = []
+    out_r = crnn_ref.forward_routed(ref, x, hip_routes(m), audit=audit)
+    note_audit(audit)
+    lr_ = crnn_ref.focal_bce(out_r, y)
+    lr_.backward()
     _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"train probabilities {c}")
     assert abs(lh.item() - lr_.item()) < 1e-5, c
     rg = dict(ref.named_parameters())
-    _grads_vs(m, lambda k: rg[k].grad, flip, str(c))
+    _grads_vs(m, lambda k: rg[k].grad, str(c))
     ref.eval()
     m.eval()
     with torch.no_grad():
@@ -209,15 +197,21 @@ def test_random_get_model_topology_vs_torch_autograd(sed, seed):
         g.load_state_dict({k.split(".", 2)[2]: v.detach() for k, v in sd.items() if k.startswith(f"grus.{i}.")})
         grus.append(g)
         width = 2 * h
-    bn_out = []
+    from oracle import crnn_ref
+    m.train()
+    out = m(x.cuda())
+    loss = sed.BCEWithLogitsLoss()(out, y.cuda())
+    loss.backward()
+    routes, audit = hip_routes(m), []
 
     def ref_fwd(x):
         h = x
         for l, (pf, pt) in enumerate(pools):
             h = F.conv2d(h, sd[f"convs.{l}.weight"], sd[f"convs.{l}.bias"], padding=1)
             h = F.batch_norm(h, None, None, sd[f"bns.{l}.weight"], sd[f"bns.{l}.bias"], training=True)
-            bn_out.append(h.detach())
-            h = F.max_pool2d(torch.relu(h), (pf, pt))
+            audit.append(crnn_ref.audit_routes(h, routes[l], pf, pt))
+            # = F.max_pool2d(torch.relu(h), (pf, pt)) with the plan's (audited) gate / arg-max decisions
+            h = crnn_ref.routed_relu_pool(h, crnn_ref.route_mask(routes[l], pf, pt, h.shape[2], h.shape[3]), pf, pt)
         b, c, f, t = h.shape
         h = h.permute(0, 3, 1, 2).reshape(b, t, c * f)
         for g in grus:
@@ -231,20 +225,7 @@ def test_random_get_model_topology_vs_torch_autograd(sed, seed):
     assert out_r.shape == (B, tp, K), msg
     loss_r = F.binary_cross_entropy_with_logits(out_r, y)
     loss_r.backward()
-    # flip-prone elements: zero crossings, and near-ties inside a live (pf x pt) window
-    flip = -1
-    for l, (z, (pf, pt)) in enumerate(zip(bn_out, pools)):
-        near = int((z.abs() < 5e-6).sum())
-        if pf * pt > 1:
-            w = F.unfold(z.reshape(-1, 1, z.shape[2], z.shape[3]), (pf, pt), stride=(pf, pt))      # [N, pf*pt, windows]
-            top = w.topk(2, dim=1).values
-            near += int((((top[:, 0] - top[:, 1]) < 5e-6) & (top[:, 0] > -5e-6)).sum())
-        if near:
-            flip = l
-    m.train()
-    out = m(x.cuda())
-    loss = sed.BCEWithLogitsLoss()(out, y.cuda())
-    loss.backward()
+    note_audit(audit)
     _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=msg)
     assert abs(loss.item() - loss_r.item()) < 1e-4, msg
 
@@ -252,7 +233,7 @@ def test_random_get_model_topology_vs_torch_autograd(sed, seed):
         if k.startswith("grus."):
             return dict(grus[int(k.split(".")[1])].named_parameters())[k.split(".", 2)[2]].grad
         return sd[k].grad
-    _grads_vs(m, want, flip, msg)
+    _grads_vs(m, want, msg)
 
 
 @pytest.mark.parametrize("H,L", [(4, 2), (20, 1), (36, 3), (100, 2), (200, 1), (340, 2)])
@@ -293,24 +274,28 @@ def test_unusual_conv_widths_vs_oracle(sed, C, cin):
     x = x * 3.0
     m.load_state_dict(ref.state_dict())
     m.cuda()
-    ref.train()
-    bn_out = []
-    hooks = [bn.register_forward_hook(lambda mod, i, o: bn_out.append(o.detach())) for bn in ref.bns]
-    out_r = ref(x)
-    for h in hooks:
-        h.remove()
-    flip = _deepest_flip_prone_block(bn_out, (2, 2, 2))
-    crnn_ref.bce_logits(out_r, y).backward()
     m.train()
     out = m(x.cuda())
     sed.BCEWithLogitsLoss()(out, y.cuda()).backward()
+    ref.train()
+    audit = []
+    out_r = crnn_ref.forward_routed(ref, x, hip_routes(m), audit=audit)
+    note_audit(audit)
+    crnn_ref.bce_logits(out_r, y).backward()
     _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-3, msg=f"C={C}")
     rg = dict(ref.named_parameters())
-    _grads_vs(m, lambda k: rg[k].grad, flip, f"C={C} cin={cin}")
+    _grads_vs(m, lambda k: rg[k].grad, f"C={C} cin={cin}")
     ref.eval()
     m.eval()
     with torch.no_grad():
         _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=1e-3, msg=f"eval C={C}")
+
+
+def test_routing_injection_tally():
+    """how many of the sweep's cases held a decision on which the plan and the oracle's own arithmetic differed (each of
+    them audited as a tie): printed so that the log says what the injected routing bought; no bound depends on it"""
+    print(f"routing injected in {ROUTED['cases']} sweep cases; in {ROUTED['with_differing_decisions']} of them at least one "
+          f"ReLU gate / arg-max was a tie that the two sides had decided differently")
 
 
 def test_many_random_topologies_run_or_refuse_cleanly(sed):

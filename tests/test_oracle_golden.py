@@ -143,3 +143,51 @@ def test_g7_g8_dataset_augment_and_packing_oracle():
     g7 = load_golden("g7_dataset.npz")
     np.testing.assert_array_equal(R.find_clean_negatives(g7["lab"], 64), g7["neg_starts"])
     np.testing.assert_array_equal(R.pool_labels(g7["lab"][60:124], 8), g7["pooled_60"])
+
+
+def test_routed_oracle_equals_the_plain_oracle_under_its_own_decisions_and_audit_refuses_wrong_ones():
+    """oracle.crnn_ref.forward_routed is how the GPU parity tests make the oracle route its gradients with the HIP plan's ReLU /
+    arg-max decisions.  It must BE the reference's forward (sed.py:106-112, crnn_lightning.py:66-73): with the decisions torch
+    itself takes (first maximum, gate = max > 0) logits and every gradient are bit-identical to the plain forward — both
+    reference variants, ragged tails, pools of 1 / 2 / 4.  And `audit_routes` must refuse a decision that is not a tie."""
+    import torch.nn.functional as F
+    from oracle import crnn_ref
+    torch.manual_seed(0)
+    for Ref, kw in ((crnn_ref.SedNetRef, dict(conv_channels=8, dropout=0.0, n_mels=13, time_pool=(2, 1, 4), gru_hidden=8)),
+                    (crnn_ref.LightningNetRef, dict(dropout=0.0, n_mels=10, time_pool=(2, 2, 2)))):
+        m = Ref(**kw)
+        m.train()
+        x = torch.randn(3, 1, kw["n_mels"], 35)
+        blocks, _, _ = crnn_ref._blocks(m)
+        routes, h = [], x
+        with torch.no_grad():
+            for conv, bn, (pf, pt) in blocks:
+                z = F.batch_norm(conv(h), None, None, bn.weight, bn.bias, training=True, eps=bn.eps)
+                B, C, Fm, T = z.shape
+                Fp, Tp = Fm // pf, T // pt
+                w = z[:, :, :Fp * pf, :Tp * pt].reshape(B, C, Fp, pf, Tp, pt).permute(0, 1, 2, 4, 3, 5).reshape(B, C, Fp, Tp, pf * pt)
+                zmax = w.max(-1).values
+                first = (w == zmax.unsqueeze(-1)).float().argmax(-1)
+                routes.append(torch.where(zmax > 0, first + 1, torch.zeros_like(first)).to(torch.uint8).permute(0, 3, 2, 1).contiguous())
+                h = F.max_pool2d(torch.relu(z), (pf, pt))
+        out0 = m(x)
+        out0.square().sum().backward()
+        g0 = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.zero_grad()
+        audit = []
+        out1 = crnn_ref.forward_routed(m, x, routes, audit=audit)
+        out1.square().sum().backward()
+        assert torch.equal(out0, out1), Ref.__name__
+        for k, p in m.named_parameters():
+            assert torch.equal(g0[k], p.grad), (Ref.__name__, k)
+        assert all(a == (0, 0, 0.0) for a in audit), audit
+    # a decision that is NOT a tie is refused: route an open window to its smaller element, or close an open gate
+    z = torch.tensor([1.0, 0.5, -1.0, -2.0]).reshape(1, 1, 1, 4)
+    ok = torch.tensor([1, 0], dtype=torch.uint8).reshape(1, 2, 1, 1)
+    assert crnn_ref.audit_routes(z, ok, 1, 2) == (0, 0, 0.0)
+    for bad in ([2, 0], [0, 0], [1, 1]):
+        with pytest.raises(AssertionError):
+            crnn_ref.audit_routes(z, torch.tensor(bad, dtype=torch.uint8).reshape(1, 2, 1, 1), 1, 2)
+    # ... while a genuine tie may go either way
+    zt = torch.tensor([1.0, 1.0 - 1e-6, 5e-6, -1.0]).reshape(1, 1, 1, 4)
+    assert crnn_ref.audit_routes(zt, torch.tensor([2, 0], dtype=torch.uint8).reshape(1, 2, 1, 1), 1, 2)[:2] == (1, 1)
