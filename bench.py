@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOAD = dict(B=128, Cin=1, F=40, T=256, C=128, H=128, gru_layers=2, dropout=0.5)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
-PROFILE_ROUNDS = ("r3", "r2", "r1")   # newest committed PMC summary first
+PROFILE_ROUNDS = ("r4", "r3", "r2", "r1")   # newest committed PMC summary first
 
 # the dominant kernel: conv2 / conv3 forward (<4, 2, false>) and their data gradients (<4, 2, true>: the same main loop with the
 # BatchNorm-backward reduction of the block below in its epilogue); one in-library timer tag covers both
@@ -62,6 +62,22 @@ def pmc_traffic_bytes():
         if n:
             return int(tot / n), rnd
     return None, None
+
+
+def forward_flops_per_batch(w):
+    """algorithmic FLOPs (2 x MAC) of one forward pass of the workload's net over one batch, SURVEY 8(d): conv_l =
+    2*9*Cin_l*C*F*T_l, GRU input projection 2*2*T'*3H*in_l, recurrence 2*2*T'*3H*H per layer, head 2*T'*2H"""
+    B, F, T, C, H = w["B"], w["F"], w["T"], w["C"], w["H"]
+    fl, cin, t = 0.0, w["Cin"], T
+    for _ in range(3):
+        fl += 2.0 * 9 * cin * C * F * t
+        cin, t = C, t // 2
+    tp, inp = t, C * F
+    for _ in range(w["gru_layers"]):
+        fl += 2.0 * 2 * tp * 3 * H * inp + 2.0 * 2 * tp * 3 * H * H
+        inp = 2 * H
+    fl += 2.0 * tp * 2 * H
+    return fl * B
 
 
 # ───────────────────────── CPU baseline (BASELINE.md §2 / SURVEY §8d) ─────────────────────────
@@ -321,6 +337,33 @@ def run_rank(args):
         torch.cuda.synchronize()
         lib.sed_prof_read(tag, C.byref(ms_x), C.byref(n_x), C.byref(units_x))
         lib.sed_prof_enable(0)
+    # ── inference: the eval-mode forward of the same net on the same resident batch (run_epoch with optim=None, sed.py:128-141:
+    # BatchNorm on running statistics folded into the conv weights, ReLU + pool in the conv epilogue, no dropout), after the
+    # timed region; SURVEY 8(d) "also report eval-forward frames/s" ──
+    eval_fwd = None
+    if rank == 0:
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                model(x)
+            em = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+            em[0].record()
+            for i in range(args.steps):
+                model(x)
+                em[i + 1].record()
+            torch.cuda.synchronize()
+        ems = sorted(em[i].elapsed_time(em[i + 1]) for i in range(args.steps))
+        e_med = ems[len(ems) // 2]
+        fl = forward_flops_per_batch(w)
+        peak_e = F32_MFMA_PEAK_TFLOPS
+        eval_fwd = {"ms": round(e_med, 4), "ms_min": round(ems[0], 4), "value": round(w["B"] * w["T"] / (e_med * 1e-3), 1), "unit": "mel-frames/s",
+                    "batches": args.steps,
+                    "roofline": {"bound": "mfma", "achieved": round(fl / (e_med * 1e-3) / 1e12, 2), "peak": peak_e, "unit": "TFLOP/s",
+                                 "frac": round(fl / (e_med * 1e-3) / 1e12 / peak_e, 4), "flops_per_batch": fl,
+                                 "ceiling_ms": round(fl / (peak_e * 1e12) * 1e3, 4),
+                                 "note": "whole eval forward (one packing launch, 3 conv blocks, 2 BiGRU layers, head) against the fp32 "
+                                         "MFMA peak: 88 % of its FLOPs are conv2/conv3, exact fp32"}}
+        model.train()
     rank_stats = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -392,6 +435,7 @@ def run_rank(args):
             out["roofline"] = {"bound": "mfma", "kernel": kname + " (conv2/conv3 forward + their data gradients)",
                                "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(tf / peak, 4), "traffic": traffic,
+                               "traffic_source": f"committed profile (profiles/{rnd}), not measured in this run",
                                "traffic_note": f"HBM bytes per launch from a separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass of this "
                                                f"command (profiles/{rnd}): (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 half-count correction",
                                "avg_launch_ms": round(avg_ms, 4), "launches": n.value,
@@ -417,6 +461,8 @@ def run_rank(args):
                     "note": "the forward instantiation, same two shapes, in 8 forward-only passes after the timed region (nothing else "
                             "on the GPU); inside the step the data gradient of conv2 shares the CUs with the top block's weight "
                             "gradient (auxiliary stream) for part of its run, which lengthens that launch and shortens the step"}
+        if eval_fwd is not None:
+            out["eval_forward"] = eval_fwd
         if not args.no_cpu_baseline and world == 1:              # rank 0 at N = 1 only (a reported baseline, not part of the step)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

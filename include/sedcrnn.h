@@ -93,6 +93,20 @@ size_t sed_conv3x3_wgrad_zero_row_bytes(int B, int Cin, int F, int T, int Cout);
 int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                          void* workspace, int B, int Cin, int F, int T, int Cout, int mode, void* stream);
 
+/* Inference (run_epoch with optim=None, sed.py:128-141; `model.eval()`): conv3x3 + BatchNorm2d on RUNNING statistics + ReLU +
+ * MaxPool2d((1,2)) (sed.py:107) in ONE launch.  BatchNorm is a per-channel affine map there, so it is folded on the way in:
+ * sed_conv3x3_pack_weights_bn_folded writes the MFMA fragments of w * scale[co] and bias_folded = bias * scale + shift with
+ * scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; the kernel's epilogue applies ReLU and the time
+ * pool to its accumulators and writes only the pooled tensor [B][T/2][F][Cout] (channels-last; a ragged last frame is dropped
+ * like nn.MaxPool2d does): in + 0.5 out bytes instead of in + 2.5 out.  x [B][T][F][Cin] channels-last.
+ * _supported: the 128-wide exact-fp32 MFMA tile with an even number of time rows (Cin % 32 == 0, Cout % 128 == 0, mel widths
+ * whose tile is <= 32 columns: 40 -> 20, 64 -> 32, ...); otherwise use sed_conv3x3_fwd_ex + sed_bn_relu_pool_drop_fwd. */
+int sed_conv3x3_bn_relu_pool_eval_supported(int B, int Cin, int F, int T, int Cout);
+int sed_conv3x3_pack_weights_bn_folded(const float* w, const float* bias, const float* gamma, const float* beta,
+                                       const float* running_mean, const float* running_var, float eps,
+                                       float* wf, float* bias_folded, int Cout, int Cin, void* stream);
+int sed_conv3x3_bn_relu_pool_eval(const float* x, const float* wp_folded, const float* bias_folded, float* pooled,
+                                  int B, int Cin, int F, int T, int Cout, void* stream);
 /* Data gradient of conv block l (the convolution of dy with wp_dgrad) FUSED with the reduction pass of the BatchNorm / ReLU /
  * max-pool / dropout backward of block l-1 (sed_bn_relu_pool_drop_bwd_reduce below), for the exact-fp32 MFMA shapes:
  * dy [B][T][F][C] -> dx [B][T][F][Cin] = gradient of block l-1's pooled output, and partials [rows][2][Cin] = per-workgroup

@@ -60,6 +60,9 @@ SIGNATURES = {
     "sed_conv3x3_wgrad_zero_row_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_wgrad": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wgrad_ex": (_i, [_fp, _i, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv3x3_bn_relu_pool_eval_supported": (_i, [_i, _i, _i, _i, _i]),
+    "sed_conv3x3_pack_weights_bn_folded": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp, _i, _i, _stream]),
+    "sed_conv3x3_bn_relu_pool_eval": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_dgrad_bnred_rows": (_i, [_i, _i, _i, _i, _i]),
     "sed_conv3x3_dgrad_bnred": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_dgrad_bnred_rg_rows": (_i, [_i, _i, _i, _i, _i, _i]),

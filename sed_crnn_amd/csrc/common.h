@@ -50,6 +50,15 @@ struct SedProfScope {
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
                                  void* stream);
 
+// internal (conv.hip): the inference form of the packing launch — every layer's fragments, the BatchNorm coefficients on running
+// statistics, BatchNorm folded into weights + bias where fold[l], and (perm_src) the GRU input weights re-ordered to
+// channels-last feature columns — see conv_pack_w_multi_k
+int sed_internal_conv_pack_eval(int n, const float* const* w, const float* const* bias, const float* const* gamma,
+                                const float* const* beta, const float* const* rm, const float* const* rv, float eps,
+                                float* const* wf, float* const* scale, float* const* shift, float* const* bias_folded, const int* fold,
+                                const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
+                                int perm_rows, int perm_C, int perm_Fp, void* stream);
+
 // internal (conv.hip): sed_conv3x3_wgrad_ex whose exact-fp32 MFMA kernels add 1 to *arrive (agent scope) as each workgroup
 // starts; _workgroups: how many that will be (0: this shape's kernel does not announce itself)
 int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw, void* workspace,

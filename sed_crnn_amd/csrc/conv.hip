@@ -35,13 +35,15 @@ struct ConvPlan {
     int rows;       // stat partial rows = B * tblocks * nft
     int nco, nci;   // small path: output channels per workgroup, input channels per launch
     size_t lds;
+    double score;   // mfma: the tile score of conv_tile (compares the even-time-row tile of the pooling epilogue with the free choice)
 };
 
 // MFMA block tile: TT time rows x FT mel columns (+1 halo each side) with TT*FT <= limit output rows (every wave always
 // runs its CV_MTW 32-row tiles, so rows below the limit are idle MFMA cycles) and at most 256*CV_NH/8 halo rows.
 // Score = useful share of the MFMA rows (tile fill x mel coverage x time coverage), discounted by the halo share that is
 // staged per tile; measured on MI355X at F=128: 32x5 125 TFLOP/s, 26x6 119, 32x4 102, 64x1 54.
-static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nft_out) {
+// pooled: the inference kernel whose epilogue pools time pairs — an even number of time rows, at most 32 mel columns.
+static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nft_out, double* score_out = nullptr, bool pooled = false) {
     double best = -1.0;
     int last_ft = -1;
     for (int nft = 1; nft <= F; ++nft) {
@@ -55,6 +57,7 @@ static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nf
         const int tt_max = (nft == 1) ? 64 : 8;
         for (int TT = 1; TT <= tt_max && TT <= T; ++TT) {
             if (TT * FT > limit || (TT + 2) * (FT + 2) * 8 > 256 * CV_NH) continue;
+            if (pooled && ((TT & 1) || FT > 32)) continue;
             if (TT > 8 && (size_t)2 * (TT + 2) * ((FT + 2) * CV_LD + CV_TPAD) * sizeof(float) > 80 * 1024) continue;
             double util = ((double)(TT * FT) / limit) * ((double)F / ((double)nf * FT)) * ((double)T / ((double)cdiv(T, TT) * TT));
             double score = util / (1.0 + 0.25 * ((double)(TT + 2) * (FT + 2) / (TT * FT) - 1.0));
@@ -62,10 +65,11 @@ static bool conv_tile(int F, int T, int limit, int* TT_out, int* FT_out, int* nf
         }
         if (FT <= 2) break;
     }
+    if (score_out) *score_out = best;
     return best > 0.0;
 }
 
-static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw) {
+static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw, bool pooled = false) {
     ConvPlan p{};
     p.kind = -1;
     p.FT = F; p.nft = 1;
@@ -74,7 +78,7 @@ static ConvPlan conv_plan(int B, int Cin, int F, int T, int Cout, int x_is_nchw)
         int nct = (Cout % 128 == 0) ? 4 : (Cout % 64 == 0 ? 2 : 1);
         int mparts = 4 / nct;
         int limit = 32 * CV_MTW * mparts;
-        if (!conv_tile(F, T, limit, &p.TT, &p.FT, &p.nft)) return p;
+        if (!conv_tile(F, T, limit, &p.TT, &p.FT, &p.nft, &p.score, pooled)) return p;
         p.kind = 1; p.nct = nct;
         p.lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
         const size_t epi = (size_t)(4 * 1024 + 256) * sizeof(float);      // epilogue: four 32x32 transpose scratches + the stat exchange
@@ -133,31 +137,103 @@ extern "C" int sed_conv3x3_pack_weights(const float* w, float* wf, float* wd, in
     return 0;
 }
 
-struct ConvPackMulti { const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int Cout[SED_MAX_CONV], Cin[SED_MAX_CONV]; };
-__global__ void conv_pack_w_multi_k(ConvPackMulti a) {
-    const int l = blockIdx.y, Cout = a.Cout[l], Cin = a.Cin[l];
+struct ConvPackMulti {
+    const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int Cout[SED_MAX_CONV], Cin[SED_MAX_CONV];
+    // inference (optional, per layer): BatchNorm on running statistics as scale = gamma / sqrt(var + eps), shift = beta - mean scale,
+    // written to scale_out / shift_out; fold != 0: the packed weights are w * scale[co] and bias_out = bias * scale + shift
+    const float* gamma[SED_MAX_CONV]; const float* beta[SED_MAX_CONV]; const float* rm[SED_MAX_CONV]; const float* rv[SED_MAX_CONV];
+    const float* bias[SED_MAX_CONV]; float* scale_out[SED_MAX_CONV]; float* shift_out[SED_MAX_CONV]; float* bias_out[SED_MAX_CONV];
+    int fold[SED_MAX_CONV]; float eps;
+    // one more slice of the grid (blockIdx.y == n): a row-major [rows][C*Fp] matrix whose columns are re-ordered from the
+    // reference's GRU feature order c*Fp + f (sed.py:108-110) to the channels-last order f*C + c of a pooled conv output
+    const float* perm_src[2]; float* perm_dst; int perm_rows, perm_C, perm_Fp;      // two sources of perm_rows rows each -> [2 perm_rows][K]
+};
+__global__ void conv_pack_w_multi_k(ConvPackMulti a, int n) {
+    const int l = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l == n) {
+        // one row per workgroup and round: read it as it lies (coalesced), write it re-ordered (coalesced) through LDS
+        extern __shared__ __attribute__((aligned(16))) float prow[];
+        const int K = a.perm_C * a.perm_Fp;
+        for (int row = blockIdx.x; row < 2 * a.perm_rows; row += gridDim.x) {
+            const float* src = a.perm_src[row >= a.perm_rows] + (size_t)(row >= a.perm_rows ? row - a.perm_rows : row) * K;
+            __syncthreads();
+            for (int k = threadIdx.x; k < K; k += blockDim.x) prow[k] = src[k];
+            __syncthreads();
+            float* dst = a.perm_dst + (size_t)row * K;
+            for (int k = threadIdx.x; k < K; k += blockDim.x) {
+                const int f = k / a.perm_C, c = k - f * a.perm_C;
+                dst[k] = prow[c * a.perm_Fp + f];
+            }
+        }
+        return;
+    }
+    const int Cout = a.Cout[l], Cin = a.Cin[l];
+    if (a.gamma[l] && i < Cout) {
+        const float sc = a.gamma[l][i] / sqrtf(a.rv[l][i] + a.eps), sh = a.beta[l][i] - a.rm[l][i] * sc;      // = bn_finalize_eval_k
+        if (a.scale_out[l]) { a.scale_out[l][i] = sc; a.shift_out[l][i] = sh; }
+        if (a.fold[l]) a.bias_out[l][i] = (a.bias[l] ? a.bias[l][i] : 0.f) * sc + sh;
+    }
     if (i >= Cout * Cin * 9) return;
     const int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
-    const float v = a.w[l][i];
+    float v = a.w[l][i];
+    if (a.fold[l]) v *= a.gamma[l][co] / sqrtf(a.rv[l][co] + a.eps);
     const bool frag = (Cin % 32 == 0) && (Cout % 32 == 0);
     if (a.wf[l]) a.wf[l][frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
     if (a.wd[l]) a.wd[l][frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+}
+static int set_lds_early(size_t bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_pack_w_multi_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { sed_set_error("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+static int pack_multi_launch(const ConvPackMulti& a, int n, void* stream) {
+    int nmax = 0;
+    for (int l = 0; l < n; ++l) {
+        const int nl = a.Cout[l] * a.Cin[l] * 9;
+        if (nl > nmax) nmax = nl;
+    }
+    const int gx = cdiv(nmax > 0 ? nmax : 1, 256);
+    const size_t lds = a.perm_src[0] ? (size_t)a.perm_C * a.perm_Fp * sizeof(float) : 0;      // one row of the re-ordered matrix
+    SED_REQUIRE(lds <= 64 * 1024, "conv_pack: a GRU input row of %zu bytes does not fit the re-ordering buffer", lds);
+    if (lds > 48 * 1024) SED_TRY(set_lds_early(lds));
+    conv_pack_w_multi_k<<<dim3(gx, n + (a.perm_src[0] ? 1 : 0)), 256, lds, as_stream(stream)>>>(a, n);
+    SED_LAUNCH_CHECK("conv_pack_w_multi");
+    return 0;
 }
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
                                  void* stream) {
     SED_REQUIRE(n > 0 && n <= SED_MAX_CONV && w && wf && wd && Cout && Cin, "conv_pack_multi: bad arguments");
     ConvPackMulti a{};
-    int nmax = 0;
     for (int l = 0; l < n; ++l) {
         SED_REQUIRE(w[l] && Cout[l] > 0 && Cin[l] > 0, "conv_pack_multi: bad layer %d", l);
         a.w[l] = w[l]; a.wf[l] = wf[l]; a.wd[l] = wd[l]; a.Cout[l] = Cout[l]; a.Cin[l] = Cin[l];
-        const int nl = Cout[l] * Cin[l] * 9;
-        if (nl > nmax) nmax = nl;
     }
-    conv_pack_w_multi_k<<<dim3(cdiv(nmax, 256), n), 256, 0, as_stream(stream)>>>(a);
-    SED_LAUNCH_CHECK("conv_pack_w_multi");
-    return 0;
+    return pack_multi_launch(a, n, stream);
+}
+// The inference form: every layer's packing, the BatchNorm coefficients on running statistics (scale / shift, for the layers
+// that still apply them in a pass of their own), the folded weights + bias of the layers whose conv epilogue pools (fold[l]),
+// and the column re-ordering of the first GRU layer's input weights when the last block's output stays channels-last — ONE launch.
+int sed_internal_conv_pack_eval(int n, const float* const* w, const float* const* bias, const float* const* gamma,
+                                const float* const* beta, const float* const* rm, const float* const* rv, float eps,
+                                float* const* wf, float* const* scale, float* const* shift, float* const* bias_folded, const int* fold,
+                                const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
+                                int perm_rows, int perm_C, int perm_Fp, void* stream) {
+    SED_REQUIRE(n > 0 && n <= SED_MAX_CONV && w && gamma && beta && rm && rv && wf && scale && shift && fold && Cout && Cin, "conv_pack_eval: bad arguments");
+    ConvPackMulti a{};
+    for (int l = 0; l < n; ++l) {
+        SED_REQUIRE(w[l] && gamma[l] && beta[l] && rm[l] && rv[l] && wf[l] && Cout[l] > 0 && Cin[l] > 0, "conv_pack_eval: bad layer %d", l);
+        SED_REQUIRE(fold[l] ? (bias_folded && bias_folded[l]) : (scale[l] && shift[l]), "conv_pack_eval: layer %d lacks its outputs", l);
+        a.w[l] = w[l]; a.wf[l] = wf[l]; a.Cout[l] = Cout[l]; a.Cin[l] = Cin[l];
+        a.gamma[l] = gamma[l]; a.beta[l] = beta[l]; a.rm[l] = rm[l]; a.rv[l] = rv[l]; a.bias[l] = bias ? bias[l] : nullptr;
+        a.scale_out[l] = scale[l]; a.shift_out[l] = shift[l]; a.bias_out[l] = bias_folded ? bias_folded[l] : nullptr; a.fold[l] = fold[l];
+    }
+    a.eps = eps;
+    if (perm_src0) {
+        SED_REQUIRE(perm_src1 && perm_dst && perm_rows > 0 && perm_C > 0 && perm_Fp > 0, "conv_pack_eval: bad permutation");
+        a.perm_src[0] = perm_src0; a.perm_src[1] = perm_src1; a.perm_dst = perm_dst; a.perm_rows = perm_rows; a.perm_C = perm_C; a.perm_Fp = perm_Fp;
+    }
+    return pack_multi_launch(a, n, stream);
 }
 
 // ── 3-term bf16-split path (EXPERIMENT, explicit opt-in: mode 1 of the *_ex entries; never the default) ──
@@ -391,7 +467,10 @@ struct ConvBnRed {
     float invXT;             // 1 / (2 TT + 2)
 };
 
-template <int NCT, int MINW, bool BNR = false, int RGC = 0>
+// EV (inference, sed.py:128-141 with optim=None): BatchNorm is folded into the packed weights and the bias on the host side of
+// the launch (running statistics are constants), and the epilogue applies ReLU + the (1,2) time pool before anything is
+// written: `y` is the POOLED output [B][T/2][F][Cout]; the un-pooled tensor never exists (in + 0.5 out bytes per block).
+template <int NCT, int MINW, bool BNR = false, int RGC = 0, bool EV = false>
 __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     const float* __restrict__ x, const float* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int Cin, int F, int T, int Cout, int TT, int FT, int nft,
@@ -399,6 +478,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     constexpr int MPARTS = 4 / NCT;
     constexpr int WROWS = 32 * NCT;
     constexpr bool RG = RGC > 0;                       // the block below is the recomputed first block with RGC input channels
+    static_assert(!EV || (NCT == 4 && !BNR && RGC == 0), "the pooled inference epilogue: one wave owns all rows of its 32 channels");
+    constexpr int EPI = EV ? 8 * 1024 + 256 : 4 * 1024 + 256;    // floats of transpose scratch (+ stat exchange) the epilogue needs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = FT + 2;
     const int HR = (TT + 2) * F2;
@@ -450,7 +531,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // MFMA loop (fp32 MFMAs occupy the VALU) this workgroup's vector instructions issue at about one per MFMA, so the
     // epilogue's duration IS its VALU instruction count x 64 cycles (measured with s_memrealtime stamps: 850 VALU instructions,
     // 22 us per workgroup, against 3.4 us with the CU to itself) — address arithmetic was half of them.
-    unsigned* rowtab = (unsigned*)(smem + (2 * HB > 4 * 1024 + 256 ? 2 * HB : 4 * 1024 + 256));
+    unsigned* rowtab = (unsigned*)(smem + (2 * HB > EPI ? 2 * HB : EPI));
     // RG: a second table (the position of a row's 3 x 4 input window in xs) and xs itself, the (FT + 2) x (2 TT + 2) patch of
     // the 1-channel network input under this tile's pooled rows (time fastest, zero outside the input)
     unsigned* xofftab = rowtab + 32 * CV_MTW * MPARTS;
@@ -460,7 +541,10 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
         const int p = (sidx & ~31) + ((sidx >> 2) & 7) + 8 * (sidx & 3);
         const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
         const bool ok = p < MROWS && t0 + tl < T && f < F;
-        rowtab[sidx] = ok ? (unsigned)(((t0 + tl) * F + f) * Cout) * 4u : 0xFFFFFFFFu;
+        if (EV)     // a row of the table = the SECOND row of a time pair that floor pooling keeps -> its pooled output row (t0 is even)
+            rowtab[sidx] = (ok && (tl & 1) && t0 + tl < (T & ~1)) ? (unsigned)((((t0 + tl) >> 1) * F + f) * Cout) * 4u : 0xFFFFFFFFu;
+        else
+            rowtab[sidx] = ok ? (unsigned)(((t0 + tl) * F + f) * Cout) * 4u : 0xFFFFFFFFu;
         if (RG) xofftab[sidx] = (unsigned)((p - tl * FT) * XT + 2 * tl);
     }
     if (RG) {
@@ -594,7 +678,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // a tile that lies wholly inside the output (the common case) skips the per-element range checks: block-uniform branch
     const bool interior = (MROWS == nMT * 32) && (t0 + TT <= T) && (f0 + FT <= F);
     // wave-uniform base of this wave's 32 channels in sequence b; a lane adds its row offset (table) and 4 c4 bytes
-    char* const yb = (char*)(y + (size_t)b * T * F * Cout + co0 + ct * 32);
+    char* const yb = (char*)(y + (size_t)b * (EV ? T >> 1 : T) * F * Cout + co0 + ct * 32);
     const char* const qb = BNR ? (const char*)(br.pooled + (size_t)b * T * F * Cout + co0 + ct * 32) : nullptr;
     // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3):
     // xhat = q (1-p)/gamma - beta/gamma = q * q_kr + q_nb
@@ -626,7 +710,36 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
 #pragma unroll
         for (int i = 0; i < CV_MTW; ++i) {
             int mt = mp + i * MPARTS;
-            if (mt < nMT) {
+            if (EV) {
+                if (mt < nMT) {
+                    // Pooled inference epilogue.  The wave owns every row of its 32 channels (mt = i), so the time pair
+                    // (tl, tl + 1) of a mel column — rows p and p + FT, FT <= 32 — lies in this tile or the previous one:
+                    // a two-tile ring of transposed tiles (8 KB per wave in the free halo buffers) holds both when the second
+                    // arrives.  Lane (rq, c4) then takes the rows rq + 8 k of this tile that close a pair: max(a, b, 0) of four
+                    // channels, one dwordx4 store to the pooled row the table names.
+                    float* ring = smem + wave * 2048;
+                    const int slot = (mt & 1) * 1024;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) ring[slot + ((j & 3) + 8 * (j >> 2) + 4 * h) * 32 + r] = acc[i][j];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const u32x4 rr = *(const u32x4*)(rowtab + mt * 32 + rq * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (rr[k] != 0xFFFFFFFFu) {
+                            const int pb = mt * 32 + rq + 8 * k;
+                            const f32x4 vb = *(const f32x4*)(ring + (pb & 63) * 32 + c4);
+                            const f32x4 va = *(const f32x4*)(ring + ((pb - FT) & 63) * 32 + c4);
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(va[e], vb[e]), 0.f);
+                            *(f32x4*)(yb + rr[k] + (unsigned)(c4 * 4)) = o;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if (mt < nMT) {
                 const u32x4 rr = *(const u32x4*)(rowtab + mt * 32 + rq * 4);              // rows rq + 8 k of this tile
                 const u32x4 ro = rr + (unsigned)(c4 * 4);
                 u32x4 xo = {0, 0, 0, 0};
@@ -733,9 +846,9 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
             }
         }
     };
-    if (interior) store_tiles(std::false_type{});
+    if (interior && !EV) store_tiles(std::false_type{});
     else store_tiles(std::true_type{});
-    if (stat) {
+    if (stat && !EV) {
         float* red = smem + 4 * 1024;               // [4 waves][2][32], behind the four transpose scratches
         if (BNR) {
             a1 *= br.inv_keep;
@@ -1109,6 +1222,62 @@ extern "C" int sed_conv3x3_fwd_ex(const float* x, int x_is_nchw, const float* wp
         }
     }
     SED_LAUNCH_CHECK("conv3x3_fwd");
+    return 0;
+}
+
+// ── inference: conv + BatchNorm (running statistics, folded) + ReLU + (1,2) time pool in one launch ──
+static size_t conv_eval_lds(const ConvPlan& p) {
+    size_t lds = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD) * sizeof(float);
+    const size_t epi = (size_t)(8 * 1024 + 256) * sizeof(float);         // the two-tile transpose ring of four waves
+    if (lds < epi) lds = epi;
+    return lds + (size_t)32 * CV_MTW * sizeof(unsigned);
+}
+// The tile of the pooling epilogue: the 128-wide exact-fp32 MFMA tile with an EVEN number of time rows (a time pair never
+// straddles two workgroups) of at most 32 mel columns (the pair lies within two consecutive 32-row tiles), two workgroups per
+// CU.  Where the free choice of conv_tile is not such a tile, the best such tile is taken if it scores within 2 % of it —
+// measured at 128 mel bins: 5 x 32 (free) 125 TFLOP/s, 6 x 26 119, 4 x 32 102: there the un-fused pair of launches is no slower,
+// so those shapes keep it (kind = -1 here).
+static ConvPlan conv_eval_plan(int B, int Cin, int F, int T, int Cout) {
+    ConvPlan none{};
+    none.kind = -1;
+    if (B <= 0 || Cin <= 0 || F <= 0 || T < 2 || Cout <= 0) return none;
+    const ConvPlan nat = conv_plan(B, Cin, F, T, Cout, 0);
+    if (nat.kind != 1 || nat.nct != 4) return none;
+    ConvPlan p = nat;
+    if ((p.TT & 1) || p.FT > 32) {
+        p = conv_plan(B, Cin, F, T, Cout, 0, true);
+        if (p.kind != 1 || p.score < 0.98 * nat.score) return none;
+    }
+    return conv_eval_lds(p) <= 80 * 1024 ? p : none;
+}
+extern "C" int sed_conv3x3_bn_relu_pool_eval_supported(int B, int Cin, int F, int T, int Cout) {
+    if (B <= 0 || Cin <= 0 || F <= 0 || T < 2 || Cout <= 0) return 0;
+    if ((size_t)B * T * F * Cin >= ((size_t)1 << 32) || (size_t)T * F * Cout >= ((size_t)1 << 30)) return 0;
+    return conv_eval_plan(B, Cin, F, T, Cout).kind == 1 ? 1 : 0;
+}
+extern "C" int sed_conv3x3_pack_weights_bn_folded(const float* w, const float* bias, const float* gamma, const float* beta,
+                                                  const float* running_mean, const float* running_var, float eps,
+                                                  float* wf, float* bias_folded, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(w && gamma && beta && running_mean && running_var && wf && bias_folded && Cout > 0 && Cin > 0, "conv3x3_pack_weights_bn_folded: bad arguments");
+    ConvPackMulti a{};
+    a.w[0] = w; a.wf[0] = wf; a.Cout[0] = Cout; a.Cin[0] = Cin; a.gamma[0] = gamma; a.beta[0] = beta; a.rm[0] = running_mean; a.rv[0] = running_var;
+    a.bias[0] = bias; a.bias_out[0] = bias_folded; a.fold[0] = 1; a.eps = eps;
+    return pack_multi_launch(a, 1, stream);
+}
+extern "C" int sed_conv3x3_bn_relu_pool_eval(const float* x, const float* wp_folded, const float* bias_folded, float* pooled,
+                                             int B, int Cin, int F, int T, int Cout, void* stream) {
+    SED_REQUIRE(x && wp_folded && bias_folded && pooled, "conv3x3_bn_relu_pool_eval: null pointer");
+    SED_REQUIRE(sed_conv3x3_bn_relu_pool_eval_supported(B, Cin, F, T, Cout), "conv3x3_bn_relu_pool_eval: shape B=%d Cin=%d F=%d T=%d Cout=%d "
+                "is not supported (sed_conv3x3_bn_relu_pool_eval_supported; use sed_conv3x3_fwd_ex + sed_bn_relu_pool_drop_fwd)", B, Cin, F, T, Cout);
+    const ConvPlan p = conv_eval_plan(B, Cin, F, T, Cout);
+    const size_t lds = conv_eval_lds(p);
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_FWD, s, 2.0 * 9.0 * Cin * Cout * (double)B * T * F);
+    dim3 grid(p.tblocks * p.nft, B, Cout / 128);
+    SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, false, 0, true>), lds));
+    conv3x3_mfma_fwd2_k<4, 2, false, 0, true><<<grid, 256, lds, s>>>(x, wp_folded, bias_folded, pooled, nullptr, B, Cin, F, T, Cout, p.TT, p.FT, p.nft,
+                                                                   1.0f / (float)p.FT, 1.0f / (float)(p.FT + 2));
+    SED_LAUNCH_CHECK("conv3x3_bn_relu_pool_eval");
     return 0;
 }
 

@@ -12,7 +12,9 @@ namespace {
 struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; float drop;
                int red_rows;      // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
                int rg_rows;       // > 0 (block 0 only): so do its weight-gradient sums (sed_conv3x3_dgrad_bnred_rg), into c1_ws
-               int rgrad; };      // recomputed first block: its weight gradient comes from the pooled output, arg-max bits and input moments   // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
+               int rgrad;         // recomputed first block: its weight gradient comes from the pooled output, arg-max bits and input moments
+               int ev; };         // inference plan only: BatchNorm folded into the packed weights, ReLU + (1,2) pool in the conv epilogue
+                                  // (sed_conv3x3_bn_relu_pool_eval): the block's un-pooled output is never written
 struct GruL { int in, H; };
 
 struct Layout {
@@ -24,6 +26,9 @@ struct Layout {
     size_t wp_f[SED_MAX_CONV], wp_d[SED_MAX_CONV], conv_out[SED_MAX_CONV], stat[SED_MAX_CONV];
     size_t mean[SED_MAX_CONV], rstd[SED_MAX_CONV], scale[SED_MAX_CONV], shift[SED_MAX_CONV];
     size_t pooled[SED_MAX_CONV], bn_sums[SED_MAX_CONV], c1_stat_ws, c1_bits, c1_mom;
+    size_t bias_f[SED_MAX_CONV];   // inference: the BatchNorm-folded conv bias of a block whose epilogue pools
+    size_t wih_perm;               // inference, last block pooled in its conv epilogue (output stays channels-last): weight_ih_l0 of both
+                                   // directions [6H][F'*C] with the columns re-ordered from c*F'+f (sed.py:108-110) to f*C+c; 0 = not used
     size_t gi[SED_MAX_GRU], gout[SED_MAX_GRU], saved[SED_MAX_GRU], gru_ws;
     size_t act[SED_MAX_DENSE];
     // backward only
@@ -80,7 +85,11 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
             SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
             q.bn_rows = sed_bn_bwd_rows(c->B, q.T, q.pt);
         }
-        size_t nout = q.fused ? 64 : (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
+        // inference: blocks >= 1 on the 128-wide exact-fp32 MFMA tile with the reference's (1,2) pool (sed.py:90) end in the pooling
+        // epilogue; everything else (and every training plan) keeps the conv output + the BatchNorm/ReLU/pool pass
+        q.ev = (!training && l > 0 && c->conv_mode == 0 && q.pf == 1 && q.pt == 2 &&
+                sed_conv3x3_bn_relu_pool_eval_supported(c->B, q.Cin, q.F, q.T, q.C)) ? 1 : 0;
+        size_t nout = (q.fused || q.ev) ? 64 : (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
         L->wp_f[l] = cv.take((size_t)9 * q.C * q.Cin);
         L->wp_d[l] = cv.take((size_t)9 * q.C * q.Cin);
         L->conv_out[l] = cv.take(nout);
@@ -88,6 +97,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         L->mean[l] = cv.take(q.C); L->rstd[l] = cv.take(q.C); L->scale[l] = cv.take(q.C); L->shift[l] = cv.take(q.C);
         L->pooled[l] = cv.take(npool);
         L->bn_sums[l] = cv.take((size_t)2 * q.C);
+        L->bias_f[l] = cv.take(q.C);
         if (npool > max_pool) max_pool = npool;
         if (q.fused) {
             // the (1,2)-pooled block takes the moment-based backward (sed_conv1_bwd_wgrad: nothing is recomputed)
@@ -134,6 +144,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     L->c1_mom = L->cv[0].rgrad ? cv.take(2 * sed_conv1_moments_doubles(L->cv[0].Cin)) : 0;                               // doubles (the carver's 256-byte granules keep them aligned)
     L->Tp = T; L->Fp = F; L->feat = Cin * F; L->M = c->B * T;
     const size_t M = (size_t)L->M;
+    // (a GRU input row of up to 64 KB: the re-ordering goes through LDS one row at a time; wider rows keep the un-fused last block)
+    if (L->cv[c->n_conv - 1].ev && (size_t)L->feat * sizeof(float) > 64 * 1024) {
+        ConvL& q = L->cv[c->n_conv - 1];
+        q.ev = 0;
+        L->conv_out[c->n_conv - 1] = cv.take((size_t)c->B * q.T * q.F * q.C);
+    }
+    L->wih_perm = (L->cv[c->n_conv - 1].ev && c->H[0] > 0) ? cv.take((size_t)6 * c->H[0] * L->feat) : 0;
     int in = L->feat, maxH = 0, max2H = 0;
     for (int i = 0; i < c->n_gru; ++i) {
         int H = c->H[i];
@@ -229,7 +246,44 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
     const int B = c->B;
     // a call that starts at phase 0 packs the weights of EVERY conv layer in one launch (exact-fp32 layouts), instead of one
     // 5 us launch per layer standing between the layers of the critical chain
-    const bool packed_up_front = pb == 0 && c->conv_mode == 0 && L.n_conv > 1;
+    // inference (no phases, exact fp32): ONE packing launch (fragments, BatchNorm coefficients on running statistics, folded
+    // weights + bias of the pooling-epilogue blocks, re-ordered GRU input weights), then one launch per conv block
+    const bool eval_plan = !training && c->conv_mode == 0 && pb == 0 && pe == 2 * L.n_conv + 1;
+    const ConvL& qtop = L.cv[L.n_conv - 1];
+    const bool wih_permuted = eval_plan && qtop.ev && L.wih_perm != 0;
+    if (eval_plan) {
+        const float* w[SED_MAX_CONV]; const float* bs[SED_MAX_CONV]; const float* gm[SED_MAX_CONV]; const float* bt[SED_MAX_CONV];
+        const float* rm[SED_MAX_CONV]; const float* rv[SED_MAX_CONV];
+        float* wf[SED_MAX_CONV]; float* sc[SED_MAX_CONV]; float* sh[SED_MAX_CONV]; float* bf[SED_MAX_CONV];
+        int fold[SED_MAX_CONV], co[SED_MAX_CONV], ci[SED_MAX_CONV];
+        for (int l = 0; l < L.n_conv; ++l) {
+            SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
+                        "net_forward: missing parameters of conv block %d", l);
+            w[l] = p->conv_w[l]; bs[l] = p->conv_b[l]; gm[l] = p->bn_g[l]; bt[l] = p->bn_b[l]; rm[l] = p->bn_rm[l]; rv[l] = p->bn_rv[l];
+            wf[l] = ws + L.wp_f[l]; sc[l] = ws + L.scale[l]; sh[l] = ws + L.shift[l]; bf[l] = ws + L.bias_f[l];
+            fold[l] = L.cv[l].ev; co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin;
+        }
+        if (wih_permuted) SED_REQUIRE(p->gru_wih[0][0] && p->gru_wih[0][1], "net_forward: missing parameters of GRU layer 0");
+        SED_TRY(sed_internal_conv_pack_eval(L.n_conv, w, bs, gm, bt, rm, rv, c->bn_eps, wf, sc, sh, bf, fold, co, ci,
+                                            wih_permuted ? p->gru_wih[0][0] : nullptr, wih_permuted ? p->gru_wih[0][1] : nullptr,
+                                            ws + L.wih_perm, 3 * L.gr[0].H, qtop.C, qtop.Fp, stream));
+        for (int l = 0; l < L.n_conv; ++l) {
+            const ConvL& q = L.cv[l];
+            const float* in = (l == 0) ? x : ws + L.pooled[l - 1];
+            const int last = (l == L.n_conv - 1);
+            if (q.fused) {
+                SED_TRY(sed_conv1_bn_relu_pool_drop_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l],
+                                                        B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, 0.f, 0, nullptr, nullptr, stream));
+            } else if (q.ev) {          // (the last block's output stays channels-last: the GRU projection reads re-ordered weights)
+                SED_TRY(sed_conv3x3_bn_relu_pool_eval(in, ws + L.wp_f[l], ws + L.bias_f[l], ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, stream));
+            } else {
+                SED_TRY(sed_conv3x3_fwd_ex(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l], nullptr, B, q.Cin, q.F, q.T, q.C, 0, stream));
+                SED_TRY(sed_bn_relu_pool_drop_fwd(ws + L.conv_out[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l], B,
+                                                  q.T, q.F, q.C, q.pf, q.pt, last, 0.f, 0, nullptr, stream));
+            }
+        }
+    }
+    const bool packed_up_front = !eval_plan && pb == 0 && c->conv_mode == 0 && L.n_conv > 1;
     if (packed_up_front) {
         const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int co[SED_MAX_CONV], ci[SED_MAX_CONV];
         for (int l = 0; l < L.n_conv; ++l) {
@@ -239,7 +293,7 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         }
         SED_TRY(sed_internal_conv_pack_multi(L.n_conv, w, wf, wd, co, ci, stream));
     }
-    for (int l = 0; l < L.n_conv; ++l) {
+    for (int l = 0; l < L.n_conv && !eval_plan; ++l) {
         const ConvL& q = L.cv[l];
         const float* in = (l == 0) ? x : ws + L.pooled[l - 1];
         const bool do_a = pb <= 2 * l && 2 * l < pe, do_b = pb <= 2 * l + 1 && 2 * l + 1 < pe;
@@ -293,12 +347,14 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
             SED_REQUIRE(p->gru_wih[i][d] && p->gru_whh[i][d] && p->gru_bih[i][d] && p->gru_bhh[i][d],
                         "net_forward: missing parameters of GRU layer %d dir %d", i, d);
         // both directions in ONE GEMM (N = 6H) when their weights/biases are adjacent (the flat arena lays them so)
-        const bool fused = p->gru_wih[i][1] == p->gru_wih[i][0] + (size_t)3 * H * K && p->gru_bih[i][1] == p->gru_bih[i][0] + 3 * H;
+        const float* wih[2] = {p->gru_wih[i][0], p->gru_wih[i][1]};
+        if (i == 0 && wih_permuted) { wih[0] = ws + L.wih_perm; wih[1] = wih[0] + (size_t)3 * H * K; }      // channels-last feature columns
+        const bool fused = wih[1] == wih[0] + (size_t)3 * H * K && p->gru_bih[i][1] == p->gru_bih[i][0] + 3 * H;
         if (fused) {
-            SED_TRY(sed_gemm_f32_ws(gin, K, 1, p->gru_wih[i][0], 1, K, ws + L.gi[i], 6 * H, p->gru_bih[i][0], M, 6 * H, K, ws + L.gemm_ws, stream));
+            SED_TRY(sed_gemm_f32_ws(gin, K, 1, wih[0], 1, K, ws + L.gi[i], 6 * H, p->gru_bih[i][0], M, 6 * H, K, ws + L.gemm_ws, stream));
         } else {
             for (int d = 0; d < 2; ++d)
-                SED_TRY(sed_gemm_f32(gin, K, 1, p->gru_wih[i][d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
+                SED_TRY(sed_gemm_f32(gin, K, 1, wih[d], 1, K, ws + L.gi[i] + d * 3 * H, 6 * H,
                                      p->gru_bih[i][d], 0.f, M, 3 * H, K, stream));
         }
         const float* whh[2] = {p->gru_whh[i][0], p->gru_whh[i][1]};
@@ -353,7 +409,7 @@ extern "C" int sed_net_workspace_region(const sed_net_cfg* c, int training, cons
     if (conv_idx) {
         const ConvL& q = L.cv[index];
         const size_t nout = (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
-        if (is("conv_out") && !q.fused) { off = L.conv_out[index]; n = nout; ok = true; }
+        if (is("conv_out") && !q.fused && !q.ev) { off = L.conv_out[index]; n = nout; ok = true; }
         else if (is("pooled")) { off = L.pooled[index]; n = npool; ok = true; }
         else if (is("mean")) { off = L.mean[index]; n = q.C; ok = true; }
         else if (is("rstd")) { off = L.rstd[index]; n = q.C; ok = true; }

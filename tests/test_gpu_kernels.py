@@ -494,6 +494,36 @@ def test_routing_codes_of_the_recomputed_first_block(ops, cin, pf, pt):
         assert torch.equal(route, want.to(torch.uint8))
 
 
+@pytest.mark.parametrize("B,T,Fm,Cin,Cout", [(2, 16, 40, 128, 128), (3, 15, 40, 32, 128), (1, 8, 64, 64, 256), (2, 23, 13, 32, 128),
+                                            (1, 4, 41, 128, 128), (2, 64, 20, 128, 128), (1, 31, 56, 32, 128), (2, 17, 70, 32, 128),
+                                            (1, 33, 8, 32, 128), (3, 9, 40, 32, 128)])
+def test_inference_conv_with_folded_batchnorm_relu_and_pool_in_the_epilogue(ops, B, T, Fm, Cin, Cout):
+    """sed_conv3x3_bn_relu_pool_eval (the eval-mode plan's conv blocks >= 1: `pool(relu(bn(conv(x))))` of sed.py:107 under
+    model.eval()) against torch: BatchNorm on running statistics folded into weights and bias, ReLU + (1,2) pool in the
+    epilogue.  Odd T (floor pooling drops the last frame), mel widths that tile to 20 / 32 / 14 / 28 columns with ragged last
+    tiles, one and two 128-channel groups, negative gamma (the fold must scale before the max), T = 2."""
+    from sed_crnn_amd._lib import lib
+    if not lib().sed_conv3x3_bn_relu_pool_eval_supported(B, Cin, Fm, T, Cout):
+        assert (T, Fm) == (9, 40)          # the one case listed for this: its best even-time-row tile scores > 2 % below the free choice
+        with pytest.raises(ValueError):
+            ops.conv3x3_bn_relu_pool_eval(torch.empty(B, T, Fm, Cin, device="cuda"), *[torch.empty(1, device="cuda")] * 6)
+        return
+    gen = torch.Generator().manual_seed(B * 1000 + T * 10 + Fm)
+    x = torch.randn(B, Cin, Fm, T, generator=gen)
+    w = torch.randn(Cout, Cin, 3, 3, generator=gen) / (3.0 * Cin ** 0.5)
+    bias, beta, rm = (torch.randn(Cout, generator=gen) * 0.3 for _ in range(3))
+    gamma = torch.rand(Cout, generator=gen) + 0.5
+    gamma[1], gamma[5] = -0.8, 0.0
+    rv = torch.rand(Cout, generator=gen) + 0.5
+    ref = F.max_pool2d(torch.relu(F.batch_norm(F.conv2d(x.double(), w.double(), bias.double(), padding=1), rm.double(), rv.double(),
+                                               gamma.double(), beta.double(), training=False, eps=1e-5)), (1, 2))
+    out = ops.conv3x3_bn_relu_pool_eval(g(x.permute(0, 3, 2, 1)), g(w), g(bias), g(gamma), g(beta), g(rm), g(rv))
+    assert out.shape == (B, T // 2, Fm, Cout)
+    close(out.permute(0, 3, 2, 1), ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-5)
+    out2 = ops.conv3x3_bn_relu_pool_eval(g(x.permute(0, 3, 2, 1)), g(w), g(bias), g(gamma), g(beta), g(rm), g(rv))
+    assert torch.equal(out, out2)
+
+
 GEMM_CASES = [(64, 64, 64), (130, 70, 50), (4096, 96, 320), (256, 384, 5120), (384, 640, 512), (33, 17, 9), (512, 768, 1024)]
 
 
