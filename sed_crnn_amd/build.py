@@ -89,7 +89,18 @@ def build(force=False, verbose=False):
             if bad:
                 os.remove(cmd[cmd.index("-o") + 1])
                 raise RuntimeError("hand-counted-waitcnt kernels must not spill:\n" + "\n".join(bad))
-            return ""                                          # the resource remarks are not warnings
+            # the resource remarks are not warnings: drop them (and their source-context lines), keep genuine diagnostics
+            keep, skip = [], 0
+            for line in r.stderr.splitlines():
+                if "remark:" in line:
+                    skip = 2                                   # a remark is followed by the quoted source line and a caret line
+                    continue
+                if skip and (line.strip().startswith(("|", "^")) or " | " in line[:12]):
+                    skip -= 1
+                    continue
+                skip = 0
+                keep.append(line)
+            return "\n".join(l for l in keep if l.strip() and "remarks generated" not in l)
         return r.stderr
 
     with ThreadPoolExecutor(max_workers=4) as ex:

@@ -1153,6 +1153,13 @@ static int set_lds(K kernel, size_t bytes) {
 static size_t dgrad_rg_lds(const ConvPlan& p, int cin1) {
     return p.lds + (size_t)32 * CV_MTW * sizeof(unsigned) + ((size_t)cin1 * (2 * p.TT + 2) * (p.FT + 2) + 4) * sizeof(float);
 }
+// The RG epilogue parks its per-wave tap sums in `red2` = floats [4352, 4352 + 4*9*cin1*32) of the LDS, without a workgroup
+// barrier; the row tables and the input patch, which slower waves may still be reading, start at float max(2 HB, 4352).  The
+// two must not meet (round-3 advisor: for small tiles, e.g. F = 8 / T = 4, they did): such shapes keep conv1_rgrad_k.
+static bool dgrad_rg_tile_ok(const ConvPlan& p, int cin1) {
+    const size_t hb2 = (size_t)2 * (p.TT + 2) * ((p.FT + 2) * CV_LD + CV_TPAD);
+    return hb2 >= (size_t)4 * 1024 + 256 + (size_t)4 * 9 * cin1 * 32;
+}
 
 extern "C" int sed_conv3x3_fwd(const float* x, int x_is_nchw, const float* wp, const float* bias, float* y,
                                float* stat, int B, int Cin, int F, int T, int Cout, void* stream) {
@@ -1316,8 +1323,10 @@ static int dgrad_bnred_impl(const float* dy, const float* wp_dgrad, float* dx, f
     dim3 grid(p.tblocks * p.nft, B, Cin / (32 * p.nct));
     if (x1) {
         const size_t lds = dgrad_rg_lds(p, cin1);
-        SED_REQUIRE(bits && rg_partials && (cin1 == 1 || cin1 == 2) && pool_f == 1 && pool_t == 2 && Ty == 2 * T && lds <= 80 * 1024,
-                    "conv3x3_dgrad_bnred_rg: needs 1 or 2 input channels, pool (1,2), an even conv time extent and a tile that leaves two workgroups per CU");
+        SED_REQUIRE(bits && rg_partials && (cin1 == 1 || cin1 == 2) && pool_f == 1 && pool_t == 2 && Ty == 2 * T && lds <= 80 * 1024 &&
+                    dgrad_rg_tile_ok(p, cin1),
+                    "conv3x3_dgrad_bnred_rg: needs 1 or 2 input channels, pool (1,2), an even conv time extent and a tile that leaves two workgroups per CU "
+                    "and room for the tap-sum exchange (sed_conv3x3_dgrad_bnred_rg_rows)");
         if (cin1 == 1) {
             SED_TRY(set_lds((conv3x3_mfma_fwd2_k<4, 2, true, 1>), lds));
             conv3x3_mfma_fwd2_k<4, 2, true, 1><<<grid, 256, lds, s>>>(dy, wp_dgrad, nullptr, dx, partials, B, C, F, T, Cin, p.TT, p.FT, p.nft,
@@ -1351,7 +1360,7 @@ extern "C" int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, f
 extern "C" int sed_conv3x3_dgrad_bnred_rg_rows(int B, int C, int F, int T, int Cin, int Cin1) {
     if (Cin1 < 1 || Cin1 > 2) return 0;
     ConvPlan p = conv_plan(B, C, F, T, Cin, 0);
-    return (p.kind == 1 && p.nct == 4 && dgrad_rg_lds(p, Cin1) <= 80 * 1024) ? p.rows : 0;
+    return (p.kind == 1 && p.nct == 4 && dgrad_rg_lds(p, Cin1) <= 80 * 1024 && dgrad_rg_tile_ok(p, Cin1)) ? p.rows : 0;
 }
 extern "C" int sed_conv3x3_dgrad_bnred_rg(const float* dy, const float* wp_dgrad, float* dx, float* partials, const float* pooled,
                                           const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,

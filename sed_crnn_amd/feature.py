@@ -67,6 +67,28 @@ def _tables(device_index, sr, n_fft, n_mels):
     return build_tables(hann_periodic(n_fft), slaney_mel_basis(sr, n_fft, n_mels), torch.device("cuda", device_index))
 
 
+_VALIDATED = {}          # (data_ptr, numel, version counter) of a caller's table blob -> its mel count
+
+
+def _validated_mels(tables):
+    """The library cannot read device memory to validate a caller's blob, and the kernel trusts its header: check it here —
+    ONCE per blob (keyed by address, size and torch's in-place version counter), not per clip: the check is a blocking
+    device-to-host copy (round-3 advisor)."""
+    key = (tables.data_ptr(), tables.numel(), tables._version)
+    n = _VALIDATED.get(key)
+    if n is None:
+        hdr = [int(v) & 0xFFFFFFFF for v in tables[:8].cpu().tolist()] if tables.numel() >= 8 else []
+        ok = (len(hdr) == 8 and hdr[0] == 0x4C4D3332 and hdr[4] == tables.numel() and 1 <= hdr[1] <= 128 and
+              ((hdr[5] == 0 and _LM_OFF_ENT + hdr[2] * 64 + hdr[1] <= hdr[4]) or
+               (hdr[5] == 1 and hdr[2] == 33 and _LM_OFF_ENT + 33 * 32 * 4 + hdr[1] * 4 <= hdr[4])))
+        if not ok:
+            raise ValueError("tables is not a blob written by feature.build_tables / sed_logmel_build_tables (bad header)")
+        if len(_VALIDATED) >= 64:
+            _VALIDATED.clear()
+        n = _VALIDATED[key] = hdr[1]
+    return n
+
+
 def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=None, std=None, tables=None):
     """y: mono float32 PCM CUDA tensor [N] -> [1 + N//hop, n_mels] log-mel energies (natural log, no eps).
     ``tables`` = build_tables(window, melfb, device) replaces librosa's default window / filterbank."""
@@ -78,14 +100,7 @@ def mbe(y, sr=SR, n_fft=NFFT, hop=HOP, n_mels=NB_MEL, pad_mode="constant", mean=
     if tables is None:
         tables = _tables(y.device.index or 0, sr, n_fft, n_mels)
     else:
-        # the library cannot read device memory to validate a caller's blob, and the kernel trusts its header: check it here
-        hdr = [int(v) & 0xFFFFFFFF for v in tables[:8].cpu().tolist()] if tables.numel() >= 8 else []
-        ok = (len(hdr) == 8 and hdr[0] == 0x4C4D3332 and hdr[4] == tables.numel() and 1 <= hdr[1] <= 128 and
-              ((hdr[5] == 0 and _LM_OFF_ENT + hdr[2] * 64 + hdr[1] <= hdr[4]) or
-               (hdr[5] == 1 and hdr[2] == 33 and _LM_OFF_ENT + 33 * 32 * 4 + hdr[1] * 4 <= hdr[4])))
-        if not ok:
-            raise ValueError("tables is not a blob written by feature.build_tables / sed_logmel_build_tables (bad header)")
-        n_mels = hdr[1]
+        n_mels = _validated_mels(tables)
     frames = 1 + y.numel() // hop
     out = torch.empty(frames, n_mels, device=y.device)
     inv = None

@@ -289,6 +289,21 @@ print("ALL-RETURNED")
     assert r.returncode == 0 and "ALL-RETURNED" in r.stdout, (r.returncode, last, r.stderr[-500:])
 
 
+def test_rg_epilogue_is_refused_for_tiles_too_small_for_its_exchange_buffer():
+    """round-3 advisor: the data gradient's RG epilogue (first block's tap sums) parks per-wave sums in LDS floats
+    [4352, 4352 + 1152 Cin1) without a workgroup barrier, while the row tables start at max(2 HB, 4352): for small tiles
+    (F = 8, T' = 4: 2 HB = 4992) the two overlapped.  Such shapes must now report 0 rows (the plan then keeps the stand-alone
+    pass), while the plain fused data gradient still takes them; the BASELINE shapes keep the RG path."""
+    from sed_crnn_amd import _lib
+    L = _lib.lib()
+    for F, Tp in ((8, 4), (8, 2)):
+        assert L.sed_conv3x3_dgrad_bnred_rows(2, 128, F, Tp, 128) > 0
+        assert L.sed_conv3x3_dgrad_bnred_rg_rows(2, 128, F, Tp, 128, 1) == 0
+        assert L.sed_conv3x3_dgrad_bnred_rg_rows(2, 128, F, Tp, 128, 2) == 0
+    for F, Tp in ((40, 128), (40, 16), (128, 256)):
+        assert L.sed_conv3x3_dgrad_bnred_rg_rows(128, 128, F, Tp, 128, 1) > 0
+
+
 # ───────────── header <-> ctypes table <-> INTEGRATION.md (round-2 verdict item 8 / advisor: a stale stub passed the stream as seed_dev) ─────────────
 def _split_top_level(s):
     out, depth, cur = [], 0, ""
