@@ -206,3 +206,10 @@ def test_bench_launches_two_ranks_and_runs_the_staged_step_on_the_hip_path():
     assert out["config"]["parallelism"] == "dp2-rehearsal-one-gpu"
     assert out["value"] > 0 and 0.2 < out["config"]["final_loss"] < 1.5
     assert out["roofline"]["launches"] == 3 * 4            # rank 0's conv forward / data-gradient launches in the timed steps
+    # the self-diagnosis of a scaling run: every rank's own median step time and the part of the gradient all-reduce that its
+    # backward did not hide (round-3 verdict item 9: the first hardware SCALE line must say where a loss comes from)
+    rk = out["ranks"]
+    assert len(rk["per_rank_ms_per_step_median"]) == 2 and all(v > 0 for v in rk["per_rank_ms_per_step_median"])
+    assert rk["ms_per_step_median_min_rank"] <= rk["ms_per_step_median_max_rank"]
+    assert 0.0 <= rk["allreduce_exposed_ms_avg"] <= rk["allreduce_exposed_ms_max_rank"] < 1e4
+    assert "eval_forward" in out and out["eval_forward"]["ms"] > 0
