@@ -55,8 +55,40 @@ __device__ __forceinline__ constexpr int brev5(int k) {
     return ((k & 1) << 4) | ((k & 2) << 2) | (k & 4) | ((k & 8) >> 2) | ((k & 16) >> 4);
 }
 
-// 32-point DIF FFT in registers, forward sign; result X[k] = a[brev5(k)].  All indices are compile-time constants.
-__device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
+// A complex point lives in ONE aligned VGPR pair (re, im): the butterfly's u + v / u - v are one v_pk_add_f32 each and a twiddle
+// multiply (dr C + di S, di C - dr S) = d * (C, C) + swap(d) * (S, -S) is v_pk_mul_f32 + v_pk_fma_f32 — hipcc folds the swap into the
+// instruction's op_sel bits, so there is no register shuffling: 259 vector instructions per 32-point transform instead of 456
+// with separate re[] / im[] arrays (round 2 found the SLP vectoriser's packing of those arrays useless: it paid for every packed
+// add with moves that built the pairs; here the pairs are how the data is loaded — global_load_dwordx2 of (x[2n], x[2n+1])).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 swp(f2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+// The forms hipcc does not find by itself (it negates and moves halves with v_xor / v_mov instead) are written with the VOP3P
+// modifiers spelled out: op_sel[i] = 1 takes the HIGH half of source i for the low result, op_sel_hi[i] = 0 the LOW half for the
+// high result; neg_lo / neg_hi negate source i for the low / high result.  Plain (non-volatile) asm: free to be scheduled.
+__device__ __forceinline__ f2 cmul(f2 x, f2 w) {               // x * w (complex): (xr wr - xi wi, xr wi + xi wr)
+    f2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(x), "v"(w));                                   // (xr wr, xi wr)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(x), "v"(w), "v"(t));   // + (-xi wi, xr wi)
+    return d;
+}
+__device__ __forceinline__ f2 sub_rot(f2 a, f2 b) {            // -i (a - b) = (a.y - b.y, b.x - a.x)
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 add_conj(f2 a, f2 b) {           // a + conj(b) = (a.x + b.x, a.y - b.y)
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f2 rot_sub_conj(f2 a, f2 b) {       // -i (a - conj(b)) = (a.y + b.y, b.x - a.x)
+    f2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// 32-point DIF FFT in registers, forward sign; result X[k] = z[brev5(k)].  All indices are compile-time constants.
+__device__ __forceinline__ void fft32(f2 (&z)[32]) {
     constexpr float C32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                                0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
                                0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
@@ -75,12 +107,11 @@ __device__ __forceinline__ void fft32(float (&re)[32], float (&im)[32]) {
             for (int j = 0; j < h; ++j) {
                 const int i0 = blk + j, i1 = i0 + h;
                 const int m = j * (16 / h);                 // twiddle W_32^m = C32[m] - i S32[m]
-                const float ur = re[i0], ui = im[i0], vr = re[i1], vi = im[i1];
-                re[i0] = ur + vr; im[i0] = ui + vi;
-                const float dr = ur - vr, di = ui - vi;
-                if (m == 0) { re[i1] = dr; im[i1] = di; }
-                else if (m == 8) { re[i1] = di; im[i1] = -dr; }
-                else { re[i1] = dr * C32[m] + di * S32[m]; im[i1] = di * C32[m] - dr * S32[m]; }
+                const f2 u = z[i0], v = z[i1];
+                z[i0] = u + v;
+                if (m == 0) z[i1] = u - v;
+                else if (m == 8) z[i1] = sub_rot(u, v);      // W_32^8 = -i
+                else { const f2 d = u - v; z[i1] = d * (f2){C32[m], C32[m]} + swp(d) * (f2){S32[m], -S32[m]}; }
             }
         }
     }
@@ -117,12 +148,15 @@ __device__ __forceinline__ void addtid_store8(unsigned base, float a0, float a1,
                    "i"((K0 + 6) * LM_ROW_BYTES), "i"((K0 + 7) * LM_ROW_BYTES)
                  : "memory");
 }
-// rows k1 = 0..31 of one component: row k1 holds X[k1] = a[brev5(k1)] of every lane
-__device__ __forceinline__ void exchange_store(unsigned base, const float (&a)[32]) {
-    addtid_store8<0>(base, a[brev5(0)], a[brev5(1)], a[brev5(2)], a[brev5(3)], a[brev5(4)], a[brev5(5)], a[brev5(6)], a[brev5(7)]);
-    addtid_store8<8>(base, a[brev5(8)], a[brev5(9)], a[brev5(10)], a[brev5(11)], a[brev5(12)], a[brev5(13)], a[brev5(14)], a[brev5(15)]);
-    addtid_store8<16>(base, a[brev5(16)], a[brev5(17)], a[brev5(18)], a[brev5(19)], a[brev5(20)], a[brev5(21)], a[brev5(22)], a[brev5(23)]);
-    addtid_store8<24>(base, a[brev5(24)], a[brev5(25)], a[brev5(26)], a[brev5(27)], a[brev5(28)], a[brev5(29)], a[brev5(30)], a[brev5(31)]);
+// rows k1 = 0..31 of one component (IMAG = 0: real parts, 1: imaginary parts): row k1 holds X[k1] = z[brev5(k1)] of every lane
+template <int IMAG>
+__device__ __forceinline__ void exchange_store(unsigned base, const f2 (&z)[32]) {
+#define LM_C(k) (IMAG ? z[brev5(k)].y : z[brev5(k)].x)
+    addtid_store8<0>(base, LM_C(0), LM_C(1), LM_C(2), LM_C(3), LM_C(4), LM_C(5), LM_C(6), LM_C(7));
+    addtid_store8<8>(base, LM_C(8), LM_C(9), LM_C(10), LM_C(11), LM_C(12), LM_C(13), LM_C(14), LM_C(15));
+    addtid_store8<16>(base, LM_C(16), LM_C(17), LM_C(18), LM_C(19), LM_C(20), LM_C(21), LM_C(22), LM_C(23));
+    addtid_store8<24>(base, LM_C(24), LM_C(25), LM_C(26), LM_C(27), LM_C(28), LM_C(29), LM_C(30), LM_C(31));
+#undef LM_C
 }
 
 __device__ __forceinline__ float pcm_at(const float* __restrict__ pcm, long n, long n_samples, int pad_mode) {
@@ -137,7 +171,9 @@ __device__ __forceinline__ float pcm_at(const float* __restrict__ pcm, long n, l
     return 0.f;
 }
 
-template <int WPB>
+// DB: the next pair's PCM goes to a second register set one iteration ahead (needs the 256 registers of <= 8 waves per CU);
+// otherwise it is loaded into the FFT registers before the mel pass of the current pair (they are dead by then)
+template <int WPB, bool DB = (WPB <= 8)>
 __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict__ pcm, long n_samples,
                                                          const uint32_t* __restrict__ tables, int table_words,
                                                          const float* __restrict__ mu, const float* __restrict__ inv_sigma,
@@ -149,14 +185,20 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         for (int i = tid; i < table_words / 4; i += WPB * 64) dst[i] = src[i];
     }
+    // the fused scaler's coefficients go to LDS too: a global load inside the loop would have to retire IN ORDER behind the
+    // PCM prefetch of the next pair (vmcnt counts in order), i.e. wait for exactly the latency the prefetch is there to hide
+    float* s_mu = lds + table_words + WPB * 2 * LM_FRAME_SCR;
+    float* s_is = s_mu + LM_MAX_MELS;
+    if (mu)
+        for (int i = tid; i < n_mels_out && i < LM_MAX_MELS; i += WPB * 64) { s_mu[i] = mu[i]; s_is[i] = inv_sigma[i]; }
     __syncthreads();
     const uint32_t* hdr = reinterpret_cast<const uint32_t*>(lds);
     // the row length of `out` is the caller's n_mels; a blob built for more bands than that never writes past a row
     const int n_mels = (int)hdr[1] < n_mels_out ? (int)hdr[1] : n_mels_out, iters = (int)hdr[2];
     const bool two_band = hdr[5] != 0;                       // which mel plan the blob carries (wave-uniform)
-    const float2* s_win = reinterpret_cast<const float2*>(lds + LM_OFF_WIN);
-    const float2* s_tw = reinterpret_cast<const float2*>(lds + LM_OFF_TW);
-    const float2* s_pw = reinterpret_cast<const float2*>(lds + LM_OFF_PW);
+    const f2* s_win = reinterpret_cast<const f2*>(lds + LM_OFF_WIN);
+    const f2* s_tw = reinterpret_cast<const f2*>(lds + LM_OFF_TW);
+    const f2* s_pw = reinterpret_cast<const f2*>(lds + LM_OFF_PW);
     const float2* s_ent = reinterpret_cast<const float2*>(lds + LM_OFF_ENT);
     const uint32_t* s_band = reinterpret_cast<const uint32_t*>(lds + LM_OFF_ENT + (size_t)iters * 64);
 
@@ -166,7 +208,6 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
     float* wscr = lds + table_words + wave * 2 * LM_FRAME_SCR;               // the wave's whole scratch: the 32 x 65 exchange buffer
     const unsigned xbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(wscr - lds) * 4u +
                                                           (unsigned)__builtin_amdgcn_groupstaticsize());
-    const float* xrow = wscr + r * (LM_ROW_BYTES / 4) + 32 * half;
     const int partner = (lane & 32) | ((32 - r) & 31);
     const bool even_hop = (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(pcm) & 7) == 0;
     const long n_pairs = (n_frames + 1) >> 1;
@@ -177,86 +218,132 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
         const long first = pair * 2 * hop - LM_NFFT / 2, last = first + hop + LM_NFFT;      // span of both frames (wave-uniform)
         return even_hop && first >= 0 && last <= n_samples && pair * 2 + 1 < n_frames;
     };
-    float re[32], im[32];
-    bool loaded = false;
+    f2 z[32];                                                // z[n] = (x[2n], x[2n+1]): one complex point per VGPR pair
+    // Where the time goes (round 4, ablation builds on one box, one hour of audio, 12 waves per CU; the full kernel 0.33-0.35 ms):
+    // without the mel pass 0.246, without the pairing pass 0.271, without the two FFTs 0.262, without any of the compute phases
+    // 0.175, of which the PCM loads are 0.11 (0.062 with the loads replaced by a register fill): the phases ADD UP — each is a
+    // chain of LDS round trips (table reads, exchange, bpermute), and neither the vector ALU (36 %) nor the LDS pipe (40-55 %)
+    // nor HBM (1.9 of 6.3 TB/s) is saturated.  What was tried on that in round 4: complex points in VGPR pairs (v_pk_* with op_sel:
+    // 38 % fewer vector instructions — no change in run time, kept: it is the smaller kernel); table and power-bin reads of the
+    // mel and pairing passes issued in batches ahead of the stores that hipcc has to order them behind (-5 %); a second
+    // register set for the next pair's PCM, loaded a whole iteration ahead (DB, needs the 256 registers of 8 waves per CU:
+    // 0.36 ms, slower than 12 waves with the loads issued before the mel pass; kept for the large-table plans that run with
+    // <= 8 waves anyway); de-phasing the waves of a SIMD by a third of an iteration (no change).
+    f2 zn[DB ? 32 : 1];
     const long stride = (long)gridDim.x * WPB;
-    for (long pair = (long)blockIdx.x * WPB + wave; pair < n_pairs; pair += stride) {
+    const long pair0 = (long)blockIdx.x * WPB + wave;
+    bool nloaded = DB && pair0 < n_pairs && fast_ok(pair0);
+    if (DB && nloaded) {
+        const f2* src = reinterpret_cast<const f2*>(pcm + (pair0 * 2 + half) * hop - LM_NFFT / 2) + r;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) zn[DB ? n1 : 0] = src[32 * n1];
+    }
+    for (long pair = pair0; pair < n_pairs; pair += stride) {
         long frame = pair * 2 + half;
         const bool live = frame < n_frames;
         if (!live) frame = n_frames - 1;                     // odd tail: the upper half recomputes the last frame, stores nothing
         const long start = frame * hop - LM_NFFT / 2;
         // ── z[32 n1 + r] = (x[64 n1 + 2r], x[64 n1 + 2r + 1]) * window ──
-        if (!loaded) {
-            if (fast_ok(pair)) {
-                const float2* src = reinterpret_cast<const float2*>(pcm + start) + r;
+        const bool loaded = nloaded;
+        if (DB && loaded) {
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) { const float2 v = src[32 * n1]; re[n1] = v.x; im[n1] = v.y; }
+            for (int n1 = 0; n1 < 32; ++n1) z[n1] = zn[DB ? n1 : 0];
+        }
+        if (DB) nloaded = pair + stride < n_pairs && fast_ok(pair + stride);
+        if (DB && nloaded) {                                 // the next pair's PCM: first use is the copy above, one iteration from now
+            const f2* src = reinterpret_cast<const f2*>(pcm + ((pair + stride) * 2 + half) * hop - LM_NFFT / 2) + r;
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) zn[DB ? n1 : 0] = src[32 * n1];
+        }
+        if (!loaded) {
+            if (!DB && fast_ok(pair)) {
+                const f2* src = reinterpret_cast<const f2*>(pcm + start) + r;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) z[n1] = src[32 * n1];
             } else {                                         // edge frames / odd hop: guarded loads, staged through LDS so that
                 wave_lds_fence();                            //  this cold path costs no registers (dynamic index, not unrolled)
 #pragma unroll 1
                 for (int n1 = 0; n1 < 32; ++n1) scr[n1 * 32 + r] = pcm_at(pcm, start + 64 * n1 + 2 * r, n_samples, pad_mode);
                 wave_lds_fence();
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) re[n1] = scr[n1 * 32 + r];
+                for (int n1 = 0; n1 < 32; ++n1) z[n1].x = scr[n1 * 32 + r];
                 wave_lds_fence();
 #pragma unroll 1
                 for (int n1 = 0; n1 < 32; ++n1) scr[n1 * 32 + r] = pcm_at(pcm, start + 64 * n1 + 2 * r + 1, n_samples, pad_mode);
                 wave_lds_fence();
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) im[n1] = scr[n1 * 32 + r];
+                for (int n1 = 0; n1 < 32; ++n1) z[n1].y = scr[n1 * 32 + r];
             }
         }
 #pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) { const float2 w = s_win[32 * n1 + r]; re[n1] *= w.x; im[n1] *= w.y; }
+        for (int n1 = 0; n1 < 32; ++n1) z[n1] *= s_win[32 * n1 + r];
 
         // ── pass 1: FFT over n1, twiddle W_1024^{r k1} ──
-        fft32(re, im);
+        fft32(z);
 #pragma unroll
         for (int k1 = 1; k1 < 32; ++k1) {
-            const float2 w = s_tw[k1 * 32 + r];
             const int b = brev5(k1);
-            const float xr = re[b], xi = im[b];
-            re[b] = xr * w.x - xi * w.y;
-            im[b] = xr * w.y + xi * w.x;
+            z[b] = cmul(z[b], s_tw[k1 * 32 + r]);
         }
         // ── exchange through LDS (real parts, then imaginary parts, the wave's 32 x 65 buffer): lane (half, r) holds
         //    A[r][k1] and stores row k1 lane-linearly; lane (half, c) then needs A[n2][c] = row c, column 32*half + n2 ──
         wave_lds_fence();                                    // the previous frame's mel pass has finished reading the scratch
-        exchange_store(xbase, re);
+        exchange_store<0>(xbase, z);
         wave_lds_fence();
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) re[n2] = xrow[n2];
+        // (single-dword reads straight into the halves of the register pairs: left to hipcc these become ds_read2_b32 into
+        // scratch pairs + 64 v_mov to split them — LDS issue slots are cheaper here than vector ones)
+        const unsigned xaddr = xbase + (unsigned)(r * LM_ROW_BYTES + 128 * half);          // LDS byte address of xrow
+#define LM_XREAD(H)                                                                                              \
+    _Pragma("unroll") for (int n2 = 0; n2 < 32; ++n2) {                                                           \
+        float t_;                                                                                                \
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(t_) : "v"(xaddr), "i"(n2 * 4));                       \
+        z[n2].H = t_;                                                                                            \
+    }                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    _Pragma("unroll") for (int n2 = 0; n2 < 32; ++n2) asm volatile("" : "+v"(z[n2]));
+        LM_XREAD(x)                                          // (the .y halves — the imaginary parts — are still to be stored)
         wave_lds_fence();
-        exchange_store(xbase, im);
+        exchange_store<1>(xbase, z);
         wave_lds_fence();
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) im[n2] = xrow[n2];
+        LM_XREAD(y)
+#undef LM_XREAD
         wave_lds_fence();
-        // ── pass 2: FFT over n2 -> Z[r + 32 k2] = (re, im)[brev5(k2)] ──
-        fft32(re, im);
+        // ── pass 2: FFT over n2 -> Z[r + 32 k2] = z[brev5(k2)] ──
+        fft32(z);
         // ── pairing: 2 X[k] = (Z[k] + conj Z[N-k]) - i W_2048^k (Z[k] - conj Z[N-k]); lane r owns k = r + 32 k2, k2 < 16, and
         //    its mirror N-k, whose Z lives in lane (32 - r) % 32, register 31 - k2 (lane 0: its own register 32 - k2) ──
+        // (the 16 pairing twiddles and the 16 mirrored points are fetched before the first power bin is stored: the stores to
+        // `scr` would otherwise fence every later table read behind them, one LDS round trip per k2)
+        f2 pwv[16], ppv[16];
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-            const int b = brev5(k2), bp = brev5(31 - k2), b0 = brev5((32 - k2) & 31);
-            const float zr = re[b], zi = im[b];
-            float pr = __shfl(re[bp], partner, 64), pi = __shfl(im[bp], partner, 64);
-            if (r == 0) { pr = re[b0]; pi = im[b0]; }
-            const int k = r + 32 * k2;
-            const float2 w = s_pw[k];
-            const float er = zr + pr, ei = zi - pi, qr = zi + pi, qi = pr - zr;
-            const float tr = w.x * qr - w.y * qi, ti = w.x * qi + w.y * qr;
-            const float ar = er + tr, ai = ei + ti, br = er - tr, bi = ei - ti;
-            scr[k] = ar * ar + ai * ai;                      // 4 |X[k]|^2   (the 1/4 is folded into the mel weights)
-            scr[LM_N - k] = br * br + bi * bi;               // 4 |X[N-k]|^2
+            const int bp = brev5(31 - k2), b0 = brev5((32 - k2) & 31);
+            pwv[k2] = s_pw[r + 32 * k2];
+            f2 pp = {__shfl(z[bp].x, partner, 64), __shfl(z[bp].y, partner, 64)};
+            if (r == 0) pp = z[b0];
+            ppv[k2] = pp;
         }
-        if (r == 0) { const float zr = re[brev5(16)], zi = im[brev5(16)]; scr[512] = 4.f * (zr * zr + zi * zi); }
-        wave_lds_fence();
-        loaded = pair + stride < n_pairs && fast_ok(pair + stride);
-        if (loaded) {                                        // prefetch the next pair's PCM; first use is the next window multiply
-            const float2* src = reinterpret_cast<const float2*>(pcm + ((pair + stride) * 2 + half) * hop - LM_NFFT / 2) + r;
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) { const float2 v = src[32 * n1]; re[n1] = v.x; im[n1] = v.y; }
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const f2 zz = z[brev5(k2)], pp = ppv[k2];
+            const int k = r + 32 * k2;
+            const f2 e = add_conj(zz, pp);                   // Z[k] + conj Z[N-k]
+            const f2 q = rot_sub_conj(zz, pp);               // -i (Z[k] - conj Z[N-k]) = (zi + pi, pr - zr)
+            const f2 t = cmul(q, pwv[k2]);
+            const f2 a = e + t, bb = e - t;
+            const f2 a2 = a * a, b2 = bb * bb;
+            scr[k] = a2.x + a2.y;                            // 4 |X[k]|^2   (the 1/4 is folded into the mel weights)
+            scr[LM_N - k] = b2.x + b2.y;                     // 4 |X[N-k]|^2
+        }
+        if (r == 0) { const f2 zz = z[brev5(16)]; scr[512] = 4.f * (zz.x * zz.x + zz.y * zz.y); }
+        wave_lds_fence();
+        if (!DB) {
+            nloaded = pair + stride < n_pairs && fast_ok(pair + stride);
+            if (nloaded) {                                   // single set: the FFT registers are dead here; first use is the next window multiply
+                const f2* src = reinterpret_cast<const f2*>(pcm + ((pair + stride) * 2 + half) * hop - LM_NFFT / 2) + r;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) z[n1] = src[32 * n1];
+            }
         }
         if (two_band) {
             // ── two-band plan: bins 33r .. 33r+32 (bins past 1024 carry zero weights; their slots are cleared so that a
@@ -267,16 +354,26 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
             const f32x4* ent = reinterpret_cast<const f32x4*>(s_ent) + r;
             const float* pb = scr + LM_TRI_BINS * r;
             float lo = 0.f, hi = 0.f;
+            // The table entries and power bins of a whole chunk are read BEFORE its first partial sum is stored: hipcc cannot
+            // prove that a store to `part` leaves `scr` and the table alone, so with read / use / store per bin (round 2) every
+            // bin paid two LDS round trips in sequence — 33 x ~250 cycles, a quarter of the kernel (ablation: 0.11 of 0.40 ms).
+            constexpr int CH = DB ? 11 : 3;                   // (12 waves per CU: 168 registers, 64 of them hold the prefetched PCM)
+            static_assert(LM_TRI_BINS % CH == 0, "chunks");
 #pragma unroll
-            for (int i = 0; i < LM_TRI_BINS; ++i) {
-                const f32x4 e = ent[i * 32];
-                const float pv = pb[i];
-                lo = fmaf(e[0], pv, lo);
-                hi = fmaf(e[1], pv, hi);
-                const uint32_t slot = __float_as_uint(e[2]);
-                if ((int32_t)slot >= 0) {
-                    *reinterpret_cast<float2*>(part + slot) = make_float2(lo, hi);
-                    lo = 0.f; hi = 0.f;
+            for (int c0 = 0; c0 < LM_TRI_BINS; c0 += CH) {
+                f32x4 e[CH];
+                float pv[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { e[u] = ent[(c0 + u) * 32]; pv[u] = pb[c0 + u]; }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    lo = fmaf(e[u][0], pv[u], lo);
+                    hi = fmaf(e[u][1], pv[u], hi);
+                    const uint32_t slot = __float_as_uint(e[u][2]);
+                    if ((int32_t)slot >= 0) {
+                        *reinterpret_cast<float2*>(part + slot) = make_float2(lo, hi);
+                        lo = 0.f; hi = 0.f;
+                    }
                 }
             }
             wave_lds_fence();
@@ -292,7 +389,7 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
                 v += part[l.w & 0xffffu];
                 v += part[l.w >> 16];
                 v = logf(v);
-                if (mu) v = (v - mu[m]) * inv_sigma[m];
+                if (mu) v = (v - s_mu[m]) * s_is[m];
                 if (live) out[frame * n_mels_out + m] = v;
             }
         } else {
@@ -319,7 +416,7 @@ __global__ __launch_bounds__(WPB * 64) void logmel_fft_k(const float* __restrict
                 float v = 0.f;
                 for (int j = 0; j < cnt; ++j) v += part[f0 + j];
                 v = logf(v);
-                if (mu) v = (v - mu[m]) * inv_sigma[m];
+                if (mu) v = (v - s_mu[m]) * s_is[m];
                 if (live) out[frame * n_mels_out + m] = v;
             }
         }
@@ -475,10 +572,11 @@ extern "C" int sed_logmel_build_tables(const float* window_host, const float* me
 
 // 12 waves per CU: the most that fit beside the tables (12 x 9.7 KB of exchange / power scratch + 38 KB of tables in 160 KB)
 #define LM_WPB 12
+#define LM_SCALER_BYTES ((size_t)2 * LM_MAX_MELS * sizeof(float))      // mean and 1/sigma of the fused scaler, behind the wave scratch
 template <int WPB>
 static int launch_logmel(const float* pcm, long n_samples, const void* tables, int words, const float* mu, const float* inv_sigma,
                          float* out, long frames, int hop, int n_mels, int pad_mode, hipStream_t s) {
-    const size_t lds = (size_t)words * 4 + (size_t)WPB * 2 * LM_FRAME_SCR * sizeof(float);
+    const size_t lds = (size_t)words * 4 + (size_t)WPB * 2 * LM_FRAME_SCR * sizeof(float) + LM_SCALER_BYTES;
     SED_REQUIRE(lds <= 160 * 1024, "logmel: tables + scratch (%zu B) exceed the 160 KiB LDS", lds);
     hipError_t e = hipFuncSetAttribute((const void*)logmel_fft_k<WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { sed_set_error("logmel: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
@@ -502,13 +600,13 @@ extern "C" int sed_logmel(const float* pcm, long n_samples, const void* tables, 
     SED_REQUIRE(pad_mode == 0 || pad_mode == 1, "logmel: pad_mode must be 0 (constant) or 1 (reflect)");
     const int words = (int)(tables_bytes / 4);
     SED_REQUIRE(tables_bytes % 16 == 0 && words >= LM_OFF_ENT + 64 + n_mels, "logmel: table blob of %zu bytes is malformed", tables_bytes);
-    SED_REQUIRE((size_t)words * 4 + (size_t)2 * 2 * LM_FRAME_SCR * sizeof(float) <= (size_t)160 * 1024,
+    SED_REQUIRE((size_t)words * 4 + (size_t)2 * 2 * LM_FRAME_SCR * sizeof(float) + LM_SCALER_BYTES <= (size_t)160 * 1024,
                 "logmel: a table blob of %zu bytes leaves no room for the FFT scratch in the 160 KiB LDS", tables_bytes);
     const long frames = 1 + n_samples / hop;
     hipStream_t s = as_stream(stream);
     // 12 waves per workgroup when the tables leave room for their scratch (the two-band plan of a Slaney bank: 38 KB); a large
     // list plan (up to 8 192 non-zeros = 67 KB of entries) runs with fewer waves per CU rather than being refused
-    const size_t per_wave = (size_t)2 * LM_FRAME_SCR * sizeof(float), room = (size_t)160 * 1024;
+    const size_t per_wave = (size_t)2 * LM_FRAME_SCR * sizeof(float), room = (size_t)160 * 1024 - LM_SCALER_BYTES;
     const size_t tb = (size_t)words * 4;
     if (tb + 12 * per_wave <= room) return launch_logmel<12>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
     if (tb + 8 * per_wave <= room) return launch_logmel<8>(pcm, n_samples, tables, words, mu, inv_sigma, out, frames, hop, n_mels, pad_mode, s);
