@@ -185,6 +185,12 @@ __global__ __launch_bounds__(256) void gemm_f32_k(
         for (; step + 2 < nsteps; ++step) {           // steady state, branch-free
             store(cur ^ 1);                            // step+1: registers -> the other LDS buffer
             load(kb + (step + 2) * GM_BK);             // step+2: global -> registers
+            // The loads must LEAVE here, a whole MFMA block before the next iteration's LDS stores wait for them.  Left to itself
+            // hipcc sinks them below the MFMA block (shorter live ranges), to just in front of the barrier: the next iteration then
+            // waited for an L2 / HBM round trip at its first ds_write with nothing but the barrier in between (round 4, found
+            // in the ISA of every instantiation).  Measured: no change at the GRU shapes (dX 0.270 ms, two-slice dW 0.292 ms) —
+            // the second workgroup of the CU was hiding that wait — but this is the order the pipeline was designed around.
+            __builtin_amdgcn_sched_barrier(0);
             compute(cur);
             __syncthreads();
             cur ^= 1;

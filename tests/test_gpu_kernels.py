@@ -772,6 +772,36 @@ def test_logmel_large_list_plans_run_with_fewer_waves_per_workgroup(ops, width, 
         feature.mbe(torch.from_numpy(y).cuda(), tables=tb[:-4].contiguous())
 
 
+@pytest.mark.parametrize("plan", ["two-band (12 waves, PCM prefetched before the mel pass)", "list (8 waves, PCM double-buffered a whole iteration ahead)"])
+def test_logmel_steady_state_of_the_persistent_loop_on_a_long_signal(ops, plan):
+    """the log-mel kernel is persistent (one workgroup per CU looping over frame pairs) and software-pipelined: the NEXT pair's
+    PCM is loaded while the current pair is transformed — into the FFT registers before the mel pass (12 waves per CU) or into
+    a second register set a whole iteration ahead (the <= 8-wave launches of large list plans).  Short clips never reach a
+    second iteration of that loop; this one runs 13 312 frames (> 2 x 256 workgroups x 12 waves x 2 frames) and compares EVERY
+    frame with the numpy restatement (feature.py:55-59; both pad modes' edges included)."""
+    from oracle import logmel_ref
+    from sed_crnn_amd import feature
+    rng = np.random.RandomState(7)
+    n = 1024 * 13311 + 517
+    tt = np.arange(n, dtype=np.float64) / 44100.0
+    y = (0.2 * np.sin(2 * np.pi * (200.0 + 3.0 * tt) * tt) + 0.05 * rng.randn(n)).astype(np.float32)
+    yg = torch.from_numpy(y).cuda()
+    if plan.startswith("two-band"):
+        ref = logmel_ref.mbe(y, pad_mode="reflect")
+        out = feature.mbe(yg, pad_mode="reflect").cpu().numpy()
+    else:
+        fb = np.zeros((40, 1025), np.float32)
+        for m in range(40):
+            fb[m, 23 * m: 23 * m + 100] = rng.rand(100).astype(np.float32) + 0.1          # 4 000 non-zeros: a list plan that runs 8 waves
+        tb = feature.build_tables(logmel_ref.hann_periodic(2048), fb, "cuda")
+        assert int(tb[5]) == 0
+        ref = np.log(logmel_ref.stft_power(y) @ fb.T)
+        out = feature.mbe(yg, tables=tb).cpu().numpy()
+    assert out.shape == ref.shape == (13312, 40)
+    np.testing.assert_allclose(out, ref, atol=1e-3, rtol=1e-4)
+    assert np.array_equal(out, (feature.mbe(yg, pad_mode="reflect") if plan.startswith("two-band") else feature.mbe(yg, tables=tb)).cpu().numpy())
+
+
 @pytest.mark.parametrize("B,Cin,Fm,T,Cout", [(2, 128, 40, 16, 128), (1, 32, 8, 8, 64), (3, 64, 40, 6, 32), (2, 128, 128, 8, 128)])
 def test_conv3x3_bf16x3_experiment_forward_and_dgrad(ops, B, Cin, Fm, T, Cout):
     """the opt-in 3-term bf16-split MFMA path (mode 1): forward, statistics partials and the data gradient (same kernel,
