@@ -113,7 +113,10 @@ int sed_conv3x3_bn_relu_pool_eval(const float* x, const float* wp_folded, const 
  * (sum g, sum g*xhat) of block l-1 — the input of sed_bn_bwd_finalize — formed in the epilogue from block l-1's own forward
  * OUTPUT `pooled` [B][T][F][Cin] (channels-last): it is > 0 exactly where the gradient passes (element kept by the dropout AND
  * ReLU gate open), g = dx / (1-p) there, and the normalised activation at the arg-max is (pooled (1-p) - beta) / gamma.
- * conv_out_below [B][Ty][Fy][Cin], mean, rstd are only read for channels whose gamma is exactly 0 (pool_f, pool_t: block l-1's
+ * That recovery divides a rounding error of eps |z| by gamma, so with a stored conv output below (conv_out_below != NULL) the
+ * channels with |gamma| < |beta| / 64 (and gamma == 0) contribute 0 to sum g*xhat here and MUST be finalised with
+ * sed_bn_bwd_finalize_small_gamma, which recomputes exactly those channels from the conv output; sum g is exact for every
+ * channel.  conv_out_below [B][Ty][Fy][Cin] is only tested for NULL here, mean / rstd are unused (kept for the signature) (pool_f, pool_t: block l-1's
  * pool, Ty / pool_t == T, Fy / pool_f == F); conv_out_below may be NULL for a block that stores none (the recomputed first
  * block: sed_conv1_bwd_apply_wgrad then supplies dgamma of those channels).  rows = sed_conv3x3_dgrad_bnred_rows(); 0 = shape not supported (use
  * sed_conv3x3_fwd_ex + sed_bn_relu_pool_drop_bwd_reduce).  Replaces a 1.5x re-read of block l-1's conv output. */
@@ -185,15 +188,27 @@ int sed_bn_relu_pool_drop_bwd_reduce(const float* y, const float* dout, const fl
                                      int pool_t, int out_tcf, float drop_p, uint64_t seed, const uint64_t* seed_dev, void* stream);
 int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
                         float* dgamma, float* dbeta, void* stream);
+/* sed_bn_bwd_finalize for partial rows that come out of sed_conv3x3_dgrad_bnred with a stored conv output below: channels
+ * with |gamma| < |beta| / 64 (incl. gamma == 0 with beta > 0) were left out of sum g*xhat there (xhat = (z - beta)/gamma loses
+ * eps |beta/gamma|) and are recomputed here from the block's conv output y [B][T][F][C]: g = dpooled/(1-p) where pooled > 0
+ * (dpooled, pooled [B][T/pool_t][F/pool_f][C] channels-last), the window searched as the forward searches it (z = fma(y, scale,
+ * shift), first maximum; sed.py:107 `pool(relu(bn(.)))`), xhat = (y_max - mean) rstd.  Same launch shape as
+ * sed_bn_bwd_finalize; the recomputation is a cold path of the workgroups that own such a channel. */
+int sed_bn_bwd_finalize_small_gamma(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
+                                    float* dgamma, float* dbeta, const float* dpooled, const float* pooled,
+                                    const float* y, const float* gamma, const float* beta, const float* mean,
+                                    const float* rstd, const float* scale, const float* shift,
+                                    int B, int T, int F, int pool_f, int pool_t, float drop_p, void* stream);
 /* The reduce pass of the block that feeds the GRU (out_tcf layout [B][T/pt][C][F/pf]) formed from that block's own pooled
  * OUTPUT and its gradient instead of the conv output: the same partial rows (sed_bn_bwd_rows) for sed_bn_bwd_finalize.
  * pooled > 0 exactly where the gradient passes, and the BatchNorm output at the arg-max is pooled*(1-p), so
- * xhat = (pooled*(1-p) - beta)/gamma; `y` (the conv output) is read only for channels with gamma == 0 and beta > 0.
+ * xhat = (pooled*(1-p) - beta)/gamma; `y` (the conv output), scale and shift are read only for channels with
+ * |gamma| < |beta| / 64 (incl. gamma == 0 with beta > 0), whose xhat is taken at the window's arg-max of the conv output.
  * _supported: out_tcf, F/pool_f a multiple of 4 and C*F/pool_f <= 16384; otherwise use sed_bn_relu_pool_drop_bwd_reduce. */
 int sed_bn_bwd_reduce_pooled_supported(int F, int C, int pool_f, int pool_t, int out_tcf);
 int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, const float* gamma, const float* beta,
-                             const float* y, const float* mean, const float* rstd, float* partials,
-                             int B, int T, int F, int C, int pool_f, int pool_t, int out_tcf, float drop_p, void* stream);
+                             const float* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                             float* partials, int B, int T, int F, int C, int pool_f, int pool_t, int out_tcf, float drop_p, void* stream);
 int sed_bn_relu_pool_drop_bwd_apply(const float* y, const float* dout, const float* scale,
                                     const float* shift, const float* mean, const float* rstd,
                                     const float* sum_g, const float* sum_gx, float* dy,
@@ -259,7 +274,11 @@ int sed_conv1_bwd_wgrad(const float* x, const float* dout, const float* pooled, 
                         const float* scale, const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                         void* workspace, int B, int Cin, int F, int T, int C, float drop_p,
                         const float* gamma, const float* beta, float* dgamma, void* stream);
-/* its assembling half alone, from partials [rows][C][1 + 9 Cin] formed elsewhere (sed_conv3x3_dgrad_bnred_rg) */
+/* its assembling half alone, from partials [rows][C][1 + 9 Cin] formed elsewhere (sed_conv3x3_dgrad_bnred_rg).
+ * sum_gx may be NULL (both entries): sum g*xhat is then formed from the block's own sums — rstd (b sum g + sum_k w_k R_k - mean
+ * sum g), exact for every gamma, where the value recovered from the pooled output, (z - beta)/gamma, loses eps |beta/gamma| — and
+ * also written to dgamma; with sum_gx given (a recomputing reduce pass, or sums all-reduced for synchronised BatchNorm) it is
+ * used as is and only gamma == 0 channels take the own value for dgamma. */
 int sed_conv1_bwd_wgrad_assemble(const float* partials, int rows, const double* moments, const float* wp, const float* bias,
                                  const float* mean, const float* rstd, const float* scale, const float* sum_g,
                                  const float* sum_gx, float* dw_oihw, float* dbias, int B, int Cin, int F, int T, int C,

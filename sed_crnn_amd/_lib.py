@@ -90,8 +90,9 @@ SIGNATURES = {
     "sed_bn_bwd_rows": (_i, [_i, _i, _i]),
     "sed_bn_relu_pool_drop_bwd_reduce": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_bn_bwd_finalize": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _stream]),
+    "sed_bn_bwd_finalize_small_gamma": (_i, [_fp, _i, _i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _stream]),
     "sed_bn_bwd_reduce_pooled_supported": (_i, [_i, _i, _i, _i, _i]),
-    "sed_bn_bwd_reduce_pooled": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _stream]),
+    "sed_bn_bwd_reduce_pooled": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _stream]),
     "sed_bn_relu_pool_drop_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _f, _u64, _fp, _stream]),
     "sed_reduce_rows": (_i, [_fp, _i, _i, _i, _fp, _stream]),
     "sed_gemm_f32": (_i, [_fp, _l, _l, _fp, _l, _l, _fp, _l, _fp, _f, _i, _i, _i, _stream]),

@@ -544,12 +544,13 @@ template <int BPK, int NT>
 __global__ __launch_bounds__(NT) void bn_bwd_reduce_pooled_tcf_k(
     const float* __restrict__ pooled, const float* __restrict__ dout, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ y, const float* __restrict__ mean,
-    const float* __restrict__ rstd, float* __restrict__ partials, int B, int T, int F, int C, int pf, int pt, float drop_p) {
+    const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ partials, int B, int T, int F, int C, int pf, int pt, float drop_p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [2][C * Fp / 4]
     const int Tp = T / pt, Fp = F / pf, F4 = Fp >> 2, n4 = C * F4, tid = threadIdx.x;
     const float keep = 1.f - drop_p, inv_keep = 1.f / keep;
     float a1[BPK], a2[BPK], kr[BPK], nb[BPK];
-    unsigned slow = 0;                                    // bit k: gamma == 0 and beta > 0
+    unsigned slow = 0;                                    // bit k: |gamma| < |beta| / 64 (incl. gamma == 0 with beta > 0): xhat from the conv output
 #pragma unroll
     for (int k = 0; k < BPK; ++k) {
         a1[k] = a2[k] = kr[k] = nb[k] = 0.f;
@@ -557,10 +558,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_pooled_tcf_k(
         if (i < n4) {
             const int c = i / F4;
             const float gm = gamma[c], bt = beta[c];
-            const float rg = gm != 0.f ? 1.0f / gm : 0.f;
+            const bool sl = gm == 0.f ? bt > 0.f : fabsf(gm) * 64.f < fabsf(bt);       // see the BNR epilogue in conv.hip
+            const float rg = (gm != 0.f && !sl) ? 1.0f / gm : 0.f;
             kr[k] = keep * rg;
             nb[k] = -bt * rg;
-            if (gm == 0.f && bt > 0.f) slow |= 1u << k;
+            if (sl) slow |= 1u << k;
         }
     }
     const long rows = (long)B * Tp;
@@ -592,19 +594,26 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_pooled_tcf_k(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (slow) {                                           // measure zero: xhat at the window's first element of the conv output
+    if (slow) {                                           // rare: xhat of the window's arg-max (searched like the forward does) from the conv output
 #pragma unroll 1
         for (int k = 0; k < BPK; ++k) {
             if (!((slow >> k) & 1u)) continue;
             const int i = tid + NT * k, c = i / F4, fp0 = (i - c * F4) * 4;
-            const float mu = mean[c], rs = rstd[c];
+            const float mu = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
             float s2 = 0.f;
             for (long r = blockIdx.x; r < rows; r += gridDim.x) {
                 const f32x4 qv = ((const f32x4*)(pooled + (size_t)r * C * Fp))[i], dv = ((const f32x4*)(dout + (size_t)r * C * Fp))[i];
                 const long b = r / Tp, tp = r - b * Tp;
                 for (int e = 0; e < 4; ++e) {
-                    const float yv = y[(((size_t)b * T + (size_t)tp * pt) * F + (size_t)(fp0 + e) * pf) * C + c];
-                    if (qv[e] > 0.f) s2 += dv[e] * ((yv - mu) * rs);
+                    if (!(qv[e] > 0.f)) continue;
+                    float best = -INFINITY, ybest = 0.f;
+                    for (int df = 0; df < pf; ++df)
+                        for (int dt = 0; dt < pt; ++dt) {
+                            const float yv = y[(((size_t)b * T + (size_t)tp * pt + dt) * F + (size_t)(fp0 + e) * pf + df) * C + c];
+                            const float zz = __builtin_fmaf(yv, sc, sh);
+                            if (zz > best) { best = zz; ybest = yv; }
+                        }
+                    s2 += dv[e] * ((ybest - mu) * rs);
                 }
             }
 #pragma unroll
@@ -632,9 +641,9 @@ extern "C" int sed_bn_bwd_reduce_pooled_supported(int F, int C, int pool_f, int 
 }
 
 extern "C" int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, const float* gamma, const float* beta,
-                                        const float* y, const float* mean, const float* rstd, float* partials,
-                                        int B, int T, int F, int C, int pf, int pt, int out_tcf, float drop_p, void* stream) {
-    SED_REQUIRE(pooled && dout && gamma && beta && y && mean && rstd && partials, "bn_bwd_reduce_pooled: null pointer");
+                                        const float* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                                        float* partials, int B, int T, int F, int C, int pf, int pt, int out_tcf, float drop_p, void* stream) {
+    SED_REQUIRE(pooled && dout && gamma && beta && y && mean && rstd && scale && shift && partials, "bn_bwd_reduce_pooled: null pointer");
     SED_TRY(check_pool("bn_bwd_reduce_pooled", B, T, F, C, pf, pt));
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_bwd_reduce_pooled: bad drop_p");
     SED_REQUIRE(sed_bn_bwd_reduce_pooled_supported(F, C, pf, pt, out_tcf),
@@ -644,7 +653,7 @@ extern "C" int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, 
     SedProfScope prof(SED_K_BN_BWD_REDUCE, as_stream(stream), 8.0 * B * C * (double)(T / pt) * (F / pf));
     const long n4 = (long)C * (F / pf / 4);
     const int nt = n4 <= 256L * BP_K ? 256 : 1024, need = cdiv(n4, nt);
-#define BP_LAUNCH(K_, NT_) bn_bwd_reduce_pooled_tcf_k<K_, NT_><<<grid, NT_, lds, as_stream(stream)>>>(pooled, dout, gamma, beta, y, mean, rstd, partials, B, T, F, C, pf, pt, drop_p)
+#define BP_LAUNCH(K_, NT_) bn_bwd_reduce_pooled_tcf_k<K_, NT_><<<grid, NT_, lds, as_stream(stream)>>>(pooled, dout, gamma, beta, y, mean, rstd, scale, shift, partials, B, T, F, C, pf, pt, drop_p)
     if (nt == 256) {
         switch (need) {
             case 1: BP_LAUNCH(1, 256); break;   case 2: BP_LAUNCH(2, 256); break;   case 3: BP_LAUNCH(3, 256); break;
@@ -661,12 +670,63 @@ extern "C" int sed_bn_bwd_reduce_pooled(const float* pooled, const float* dout, 
     return 0;
 }
 
+// The channels the fused reductions cannot serve (see ConvBnRed in conv.hip): |gamma| < |beta| / 64, incl. gamma == 0 with
+// beta > 0.  Their sum g*xhat is recomputed HERE, by the two-channel workgroup that finalises them, from the tensors the exact
+// xhat lives in: g = dpooled / (1-p) where the block's pooled output is > 0 (kept AND gate open), the window of the conv output
+// searched exactly as the forward and the apply pass search it (z = fma(y, scale, shift), first maximum), xhat = (y_max - mean)
+// rstd.  A cold path (such channels are rare) inside a launch that exists anyway; fixed order (thread slices, lane tree, wave
+// order): deterministic.
+struct BnSmallGamma {
+    const float* dpooled;    // [B][Tp][Fp][C] gradient of the block's pooled output (channels-last)
+    const float* pooled;     // [B][Tp][Fp][C] the pooled output itself
+    const float* y;          // [B][T][F][C] conv output
+    const float* gamma; const float* beta; const float* mean; const float* rstd; const float* scale; const float* shift;
+    int B, T, F, pf, pt; float inv_keep;
+};
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_k(const float* __restrict__ part, int rows, int C, float* sum_g,
-                                                          float* sum_gx, float* dgamma, float* dbeta) {
+                                                          float* sum_gx, float* dgamma, float* dbeta, BnSmallGamma sg) {
     __shared__ double sred[16][2][2];
     const int c = blockIdx.x * 2 + (threadIdx.x & 1);
     double A, Q;
     bn_two_channel_sums(part, rows, C, c, c < C, sred, &A, &Q);      // same layout [rows][2][C] as the forward statistics
+    if (sg.y) {
+        bool small = false;
+        if (c < C) {
+            const float gm = sg.gamma[c], bt = sg.beta[c];
+            small = gm == 0.f ? bt > 0.f : fabsf(gm) * 64.f < fabsf(bt);
+        }
+        if (__syncthreads_or(small)) {                     // workgroup-uniform: almost never taken
+            __shared__ double sq[16][2];
+            const int Tp = sg.T / sg.pt, Fp = sg.F / sg.pf;
+            const long npos = (long)sg.B * Tp * Fp;
+            double q = 0.0;
+            if (small) {
+                const float mu = sg.mean[c], rs = sg.rstd[c], sc = sg.scale[c], sh = sg.shift[c];
+                for (long pos = threadIdx.x >> 1; pos < npos; pos += 512) {
+                    if (!(sg.pooled[pos * C + c] > 0.f)) continue;
+                    const long bt_ = pos / Fp, fp = pos - bt_ * Fp, b = bt_ / Tp, tp = bt_ - b * Tp;
+                    float best = -INFINITY, ybest = 0.f;
+                    for (int df = 0; df < sg.pf; ++df)
+                        for (int dt = 0; dt < sg.pt; ++dt) {
+                            const float yv = sg.y[((b * sg.T + tp * sg.pt + dt) * sg.F + fp * sg.pf + df) * C + c];
+                            const float zz = __builtin_fmaf(yv, sc, sh);
+                            if (zz > best) { best = zz; ybest = yv; }
+                        }
+                    q += (double)(sg.dpooled[pos * C + c] * sg.inv_keep) * (double)((ybest - mu) * rs);
+                }
+            }
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+            for (int o = 2; o < 64; o <<= 1) q += __shfl_xor(q, o, 64);
+            if (lane < 2) sq[wv][lane] = q;
+            __syncthreads();
+            if (threadIdx.x < 2 && small) {
+                double t = 0.0;
+                for (int w = 0; w < 16; ++w) t += sq[w][threadIdx.x];
+                Q = t;
+            }
+        }
+    }
     if (threadIdx.x < 2 && c < C) {
         sum_g[c] = (float)A;
         sum_gx[c] = (float)Q;
@@ -678,8 +738,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_k(const float* __restric
 extern "C" int sed_bn_bwd_finalize(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
                                    float* dgamma, float* dbeta, void* stream) {
     SED_REQUIRE(partials && sum_g && sum_gx && rows > 0 && C > 0, "bn_bwd_finalize: bad arguments");
-    bn_bwd_finalize_k<<<cdiv(C, 2), 1024, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta);
+    bn_bwd_finalize_k<<<cdiv(C, 2), 1024, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta, BnSmallGamma{});
     SED_LAUNCH_CHECK("bn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int sed_bn_bwd_finalize_small_gamma(const float* partials, int rows, int C, float* sum_g, float* sum_gx,
+                                               float* dgamma, float* dbeta, const float* dpooled, const float* pooled,
+                                               const float* y, const float* gamma, const float* beta, const float* mean,
+                                               const float* rstd, const float* scale, const float* shift,
+                                               int B, int T, int F, int pf, int pt, float drop_p, void* stream) {
+    SED_REQUIRE(partials && sum_g && sum_gx && rows > 0 && C > 0, "bn_bwd_finalize_small_gamma: bad arguments");
+    SED_REQUIRE(dpooled && pooled && y && gamma && beta && mean && rstd && scale && shift, "bn_bwd_finalize_small_gamma: null pointer");
+    SED_TRY(check_pool("bn_bwd_finalize_small_gamma", B, T, F, C, pf, pt));
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "bn_bwd_finalize_small_gamma: drop_p=%f out of [0,1)", drop_p);
+    BnSmallGamma sg{dpooled, pooled, y, gamma, beta, mean, rstd, scale, shift, B, T, F, pf, pt, 1.f / (1.f - drop_p)};
+    bn_bwd_finalize_k<<<cdiv(C, 2), 1024, 0, as_stream(stream)>>>(partials, rows, C, sum_g, sum_gx, dgamma, dbeta, sg);
+    SED_LAUNCH_CHECK("bn_bwd_finalize_small_gamma");
     return 0;
 }
 

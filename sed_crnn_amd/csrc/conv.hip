@@ -449,14 +449,20 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_c_k(
 // the dropout hash:   q = relu(max z) * keep_mask / (1-p)  is > 0 exactly where the gradient passes (kept AND gate open),
 //   g = y / (1-p) there (0 elsewhere),   and the BatchNorm output at the arg-max is z = q (1-p), so xhat = (z - beta) / gamma.
 // `stat` then receives (sum g, sum g*xhat) per block in the layout of the forward statistics (= sed_bn_bwd_finalize's
-// input).  A channel with gamma == 0 (z constant; measure zero) cannot recover xhat from z: if beta > 0 its xhat is read from
-// the conv output at the window's first element (arg-max of a tie), if beta <= 0 nothing passes and both sums are 0.
+// input).  Recovering xhat from z divides a rounding error of eps |z| by gamma: for |gamma| << |beta| (z = gamma xhat + beta is
+// nearly constant) it is lost — eps |beta / gamma| — and for gamma == 0 it does not exist (round-3 advisor).  Such channels
+// contribute 0 to sum g*xhat here (sum g is exact for every channel) and get that sum from where the exact xhat is:
+//   * a block below that stores its conv output: |gamma| < |beta| / 64 (error bound 4e-6 on the fast path) — the finalising
+//     kernel recomputes those channels from the conv output, searching each window as the forward does
+//     (sed_bn_bwd_finalize_small_gamma; a cold path inside a launch that exists anyway);
+//   * a recomputed first block: gamma == 0 only here; its own passes form sum g*xhat for every channel (conv1_wgrad_assemble_k
+//     exactly, from the R_k; the recomputing apply pass for gamma == 0).
 struct ConvBnRed {
     const float* pooled;     // [B][T][F][Cout] forward output of the block whose BatchNorm is being differentiated
     const float* gamma;      // [Cout]
     const float* beta;       // [Cout]
-    const float* ybelow;     // its conv output [B][Ty][Fy][Cout] and batch statistics: read for channels with gamma == 0 only
-    const float* mean;
+    const float* ybelow;     // != NULL: the block below stores its conv output — channels whose xhat cannot be recovered from the pooled
+    const float* mean;       // output (|gamma| < |beta| / 64) then contribute 0 here and are recomputed by sed_bn_bwd_finalize_small_gamma
     const float* rstd;
     float keep, inv_keep;    // 1 - p, 1 / (1 - p)
     int pf, pt, Fy, Ty;      // pool and the extents of ybelow
@@ -683,20 +689,18 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
     // BNR: per-lane constants of this lane's four channels (transposed phase: lane = row group rq, channels c4..c4+3):
     // xhat = q (1-p)/gamma - beta/gamma = q * q_kr + q_nb
     f32x4 q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-    unsigned slowmask = 0;                           // bit e: gamma == 0 and beta > 0 (xhat from the conv output)
     if (BNR) {
         const int cb = co0 + ct * 32 + c4;
         const f32x4 q_beta = *(const f32x4*)(br.beta + cb);
         const f32x4 gm = *(const f32x4*)(br.gamma + cb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float rg = gm[e] != 0.f ? 1.0f / gm[e] : 0.f;
+            const bool zero = gm[e] == 0.f || (br.ybelow != nullptr && fabsf(gm[e]) * 64.f < fabsf(q_beta[e]));
+            const float rg = zero ? 0.f : 1.0f / gm[e];
             q_kr[e] = br.keep * rg;
             q_nb[e] = -q_beta[e] * rg;
-            if (gm[e] == 0.f && q_beta[e] > 0.f) slowmask |= 1u << e;
         }
     }
-    const bool anyslow = BNR && __builtin_amdgcn_ballot_w64(slowmask != 0) != 0;     // wave-uniform, measure zero
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     // RG: the first block's weight-gradient sums R[kh*3+kw] = sum g~ x[f+kh-1][2t'+sel+kw-1] (sel = the arg-max bit), which
     // conv1_rgrad_k otherwise forms in a pass of its own over dx (this kernel's output), the pooled tensor and the bits: 750 MB
@@ -800,28 +804,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_mfma_fwd2_k(
                         f32x4 g0;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g0[e] = pq[k][e] > 0.f ? v[e] : 0.f;
-                        if (!anyslow) {
-                            a1 += g0;
-                            a2 += g0 * (pq[k] * q_kr + q_nb);
-                        } else {
-                            const int p = mt * 32 + rq + 8 * k;
-                            const int tl = sed_fdiv(p, invF), f = f0 + p - tl * FT;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float pv = pq[k][e];
-                                float xh = pv * q_kr[e] + q_nb[e];
-                                if ((slowmask >> e) & 1u) {   // gamma == 0, beta > 0: every window is a tie, the arg-max is its first
-                                    const int cc = co0 + ct * 32 + c4 + e;                      // element: xhat from the conv output
-                                    xh = 0.f;                 // (no stored conv output: the block's own apply pass supplies this dgamma)
-                                    if (br.ybelow) {
-                                        const float yv = br.ybelow[(((size_t)b * br.Ty + (size_t)(t0 + tl) * br.pt) * br.Fy + (size_t)f * br.pf) * Cout + cc];
-                                        xh = (yv - br.mean[cc]) * br.rstd[cc];
-                                    }
-                                }
-                                a1[e] += g0[e];
-                                a2[e] += g0[e] * xh;
-                            }
-                        }
+                        a1 += g0;
+                        a2 += g0 * (pq[k] * q_kr + q_nb);
                         if (RG) {
                             f32x4 g1;                         // the share of the window's second time row
 #pragma unroll

@@ -695,7 +695,23 @@ __global__ __launch_bounds__(256) void conv1_wgrad_assemble_k(
     __syncthreads();
     if (wv != 0) return;
     const double b = bias ? (double)bias[co] : 0.0, mu = mean[co], rs = rstd[co], sc = scale[co];
-    const double sg = (double)sum_g[co] / count, sgx = (double)sum_gx[co] / count;
+    // sum g * xhat of this channel EXACTLY, from the same R_k the weight gradient is made of:
+    //   sum g xhat = rstd (sum g y - mean sum g),   sum g y = b sum g + sum_k w_k R_k   (y = b + sum_k w_k v_k at the arg-max).
+    // The value the data gradient's epilogue forms from the pooled output — xhat = (z - beta)/gamma — loses eps |beta / gamma| for a
+    // small |gamma| and does not exist for gamma == 0 (round-3 advisor); this block keeps no conv output to fall back on.  With
+    // sum_gx == NULL the block's own sums are used for EVERY channel, in the weight / bias gradient below and as dgamma (the
+    // plan's single-device path).  With sum_gx given (sums of a recomputing reduce pass, or all-reduced over ranks for
+    // synchronised BatchNorm, where the local R_k are not the global ones) it is used, and the own value only replaces dgamma of
+    // gamma == 0 channels, as before.
+    double wr = 0.0, ws1 = 0.0;
+    for (int k2 = 0; k2 < NK; ++k2) {
+        const double w2 = (double)wp[((size_t)(k2 / Cin) * C + co) * Cin + (k2 % Cin)];
+        ws1 += w2 * gram[k2];
+        wr += w2 * sv[1 + k2];
+    }
+    const double sgx_sum = rs * (b * sv[0] + wr - mu * sv[0]);
+    const bool own = sum_gx == nullptr;
+    const double sg = (double)sum_g[co] / count, sgx = (own ? sgx_sum : (double)sum_gx[co]) / count;
     if (lane < NK) {
         const int k = lane;
         double wg = 0.0;                                       // sum_k' w_k' G(k, k')
@@ -709,16 +725,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_assemble_k(
         dw[((size_t)co * Cin + ci) * 9 + tap] = (float)val;
     }
     if (lane == 63) {
-        double ws1 = 0.0, wr = 0.0;
-        for (int k2 = 0; k2 < NK; ++k2) {
-            const double w2 = (double)wp[((size_t)(k2 / Cin) * C + co) * Cin + (k2 % Cin)];
-            ws1 += w2 * gram[k2];
-            wr += w2 * sv[1 + k2];
-        }
         const double sum_y = count * b + ws1;
         db[co] = (float)(sc * (sv[0] - count * sg - sgx * rs * (sum_y - count * mu)));
-        if (dgamma && gamma && beta && gamma[co] == 0.f && beta[co] > 0.f)       // see sed_conv1_bwd_apply_wgrad
-            dgamma[co] = (float)(rs * (b * sv[0] + wr - mu * sv[0]));
+        if (dgamma && (own || (gamma && beta && gamma[co] == 0.f && beta[co] > 0.f))) dgamma[co] = (float)sgx_sum;
     }
 }
 
@@ -917,7 +926,7 @@ extern "C" int sed_conv1_bwd_wgrad_assemble(const float* partials, int rows, con
                                             const float* mean, const float* rstd, const float* scale, const float* sum_g,
                                             const float* sum_gx, float* dw_oihw, float* dbias, int B, int Cin, int F, int T, int C,
                                             const float* gamma, const float* beta, float* dgamma, void* stream) {
-    SED_REQUIRE(partials && moments && wp && mean && rstd && scale && sum_g && sum_gx && dw_oihw && dbias, "conv1_bwd_wgrad_assemble: null pointer");
+    SED_REQUIRE(partials && moments && wp && mean && rstd && scale && sum_g && dw_oihw && dbias, "conv1_bwd_wgrad_assemble: null pointer");
     SED_REQUIRE(rows > 0 && B > 0 && Cin >= 1 && Cin <= 4 && F > 0 && T > 0 && C > 0, "conv1_bwd_wgrad_assemble: bad shape");
     conv1_wgrad_assemble_k<<<C, 256, 0, as_stream(stream)>>>(partials, rows, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
                                                              (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);
@@ -933,7 +942,7 @@ extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const floa
                                    const float* scale, const float* sum_g, const float* sum_gx, float* dw_oihw, float* dbias,
                                    void* workspace, int B, int Cin, int F, int T, int C, float drop_p,
                                    const float* gamma, const float* beta, float* dgamma, void* stream) {
-    SED_REQUIRE(x && dout && pooled && argmax_bits && moments && wp && mean && rstd && scale && sum_g && sum_gx && dw_oihw && dbias && workspace,
+    SED_REQUIRE(x && dout && pooled && argmax_bits && moments && wp && mean && rstd && scale && sum_g && dw_oihw && dbias && workspace,
                 "conv1_bwd_wgrad: null pointer");
     SED_REQUIRE(sed_conv1_rgrad_supported(Cin, F, T, C, 1, 2), "conv1_bwd_wgrad: shape Cin=%d F=%d T=%d C=%d is not supported", Cin, F, T, C);
     SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "conv1_bwd_wgrad: drop_p=%f out of [0,1)", drop_p);

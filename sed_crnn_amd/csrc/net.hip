@@ -476,7 +476,12 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
     SED_REQUIRE(g->conv_w[l] && g->conv_b[l] && g->bn_g[l] && g->bn_b[l], "net_backward: missing gradient buffers of conv block %d", l);
     float* sum_g = ws + L.sum_g;
     float* sum_gx = sum_g + q.C;
-    if ((part & 1) && q.red_rows > 0) {       // the partial sums already lie in bn_part (epilogue of the data gradient above)
+    if ((part & 1) && q.red_rows > 0 && !q.fused) {   // the partial sums already lie in bn_part (epilogue of the data gradient above);
+        // channels whose xhat the pooled output cannot give (|gamma| < |beta| / 64) are recomputed from the stored conv output
+        SED_TRY(sed_bn_bwd_finalize_small_gamma(ws + L.bn_part, q.red_rows, q.C, sum_g, sum_gx, g->bn_g[l], g->bn_b[l], ws + L.gradA,
+                                                ws + L.pooled[l], ws + L.conv_out[l], p->bn_g[l], p->bn_b[l], ws + L.mean[l], ws + L.rstd[l],
+                                                ws + L.scale[l], ws + L.shift[l], B, q.T, q.F, q.pf, q.pt, q.drop, st));
+    } else if ((part & 1) && q.red_rows > 0) {
         SED_TRY(sed_bn_bwd_finalize(ws + L.bn_part, q.red_rows, q.C, sum_g, sum_gx, g->bn_g[l], g->bn_b[l], st));
     } else if (part & 1) {
         if (q.fused)
@@ -486,7 +491,7 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
         else if (sed_bn_bwd_reduce_pooled_supported(q.F, q.C, q.pf, q.pt, last))
             // the block that feeds the GRU: the sums from its pooled output and that tensor's gradient (1/pt of the conv output)
             SED_TRY(sed_bn_bwd_reduce_pooled(ws + L.pooled[l], ws + L.gradA, p->bn_g[l], p->bn_b[l], ws + L.conv_out[l],
-                                             ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, st));
+                                             ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], ws + L.shift[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf, q.pt, last, q.drop, st));
         else
             SED_TRY(sed_bn_relu_pool_drop_bwd_reduce(ws + L.conv_out[l], ws + L.gradA, ws + L.scale[l], ws + L.shift[l],
                                                      ws + L.mean[l], ws + L.rstd[l], ws + L.bn_part, B, q.T, q.F, q.C, q.pf,
@@ -496,12 +501,14 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
     if (part & 2) {
         if (count_scale != 1.f) SED_TRY(sed_scale(sum_g, 2 * q.C, 1.f / count_scale, st));   // global sums / global count
         if (q.fused && q.rgrad && q.rg_rows > 0) {         // the sums came out of the data gradient above: assemble only
+            // (single device: sum g*xhat from the block's own R_k, exact for every gamma; synchronised BatchNorm: the all-reduced sums)
             SED_TRY(sed_conv1_bwd_wgrad_assemble(ws + L.c1_ws, q.rg_rows, (const double*)(ws + L.c1_mom), ws + L.wp_f[l], p->conv_b[l],
-                                                 ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, sum_gx, g->conv_w[l], g->conv_b[l],
+                                                 ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, count_scale == 1.f ? nullptr : sum_gx, g->conv_w[l], g->conv_b[l],
                                                  B, q.Cin, q.F, q.T, q.C, p->bn_g[l], p->bn_b[l], g->bn_g[l], st));
         } else if (q.fused && q.rgrad) {
             SED_TRY(sed_conv1_bwd_wgrad(x, ws + L.gradA, ws + L.pooled[l], (const unsigned char*)(ws + L.c1_bits), (const double*)(ws + L.c1_mom),
-                                        ws + L.wp_f[l], p->conv_b[l], ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g, sum_gx,
+                                        ws + L.wp_f[l], p->conv_b[l], ws + L.mean[l], ws + L.rstd[l], ws + L.scale[l], sum_g,
+                                        (count_scale == 1.f && q.red_rows > 0) ? nullptr : sum_gx,
                                         g->conv_w[l], g->conv_b[l], ws + L.c1_ws, B, q.Cin, q.F, q.T, q.C, q.drop,
                                         q.red_rows > 0 ? p->bn_g[l] : nullptr, q.red_rows > 0 ? p->bn_b[l] : nullptr,
                                         q.red_rows > 0 ? g->bn_g[l] : nullptr, st));
@@ -534,7 +541,7 @@ static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p,
         return sed_conv3x3_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                        p->bn_g[l - 1], p->bn_b[l - 1],
                                        u.fused ? nullptr : ws + L.conv_out[l - 1],      // a recomputed first block keeps no conv output: its
-                                       ws + L.mean[l - 1], ws + L.rstd[l - 1],          // gamma == 0 channels are finished by its apply pass
+                                       ws + L.mean[l - 1], ws + L.rstd[l - 1],          // small-gamma channels are finished by its own passes
                                        u.drop, u.pf, u.pt, u.F, u.T, c->B, q.C, q.F, q.T, q.Cin, st);
     return sed_conv3x3_fwd_ex(ws + L.dconv[l], 0, ws + L.wp_d[l], nullptr, ws + L.gradA, nullptr, c->B, q.C, q.F, q.T, q.Cin, c->conv_mode, st);
 }

@@ -119,7 +119,7 @@ def bn_relu_pool_drop_bwd(y, dout, scale, shift, mean, rstd, pool_f, pool_t, out
     return dy, dgamma, dbeta, dbias
 
 
-def bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, y, mean, rstd, pool_f, pool_t, drop_p=0.0):
+def bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, y, mean, rstd, pool_f, pool_t, drop_p=0.0, scale=None, shift=None):
     """(sum g, sum g*xhat) of the GRU-feeding block from its pooled output [B,Tp,C,Fp] and that tensor's gradient
     (sed_bn_bwd_reduce_pooled + sed_bn_bwd_finalize); y [B,T,F,C] is read for gamma == 0 channels only"""
     B, T, F, Cc = y.shape
@@ -127,15 +127,18 @@ def bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, y, mean, rstd, pool_f, po
         raise ValueError("bn_bwd_sums_from_pooled: shape not supported")
     rows = lib().sed_bn_bwd_rows(B, T, pool_t)
     part = torch.empty(rows, 2, Cc, device=y.device)
+    if scale is None:                                  # the fused coefficients as sed_bn_finalize_train forms them
+        scale = gamma * rstd
+        shift = beta - mean * scale
     check(lib().sed_bn_bwd_reduce_pooled(ptr(_f32c(pooled)), ptr(_f32c(dout)), ptr(gamma), ptr(beta), ptr(_f32c(y)), ptr(mean),
-                                         ptr(rstd), ptr(part), B, T, F, Cc, pool_f, pool_t, 1, drop_p, stream_ptr()),
+                                         ptr(rstd), ptr(scale), ptr(shift), ptr(part), B, T, F, Cc, pool_f, pool_t, 1, drop_p, stream_ptr()),
           "bn_bwd_reduce_pooled")
     sum_g, sum_gx = torch.empty(Cc, device=y.device), torch.empty(Cc, device=y.device)
     check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cc, ptr(sum_g), ptr(sum_gx), None, None, stream_ptr()), "bn_bwd_finalize")
     return sum_g, sum_gx
 
 
-def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0):
+def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0, scale=None, shift=None):
     """data gradient of a conv block + the BatchNorm-backward sums of the block below in its epilogue
     -> (dx [B,T,F,Cin], sum_g [Cin], sum_gx [Cin]); dy [B,T,F,C], wd = the dgrad packing [9,Cin,C]"""
     B, T, F, Cc = dy.shape
@@ -144,11 +147,18 @@ def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f
     assert rows > 0, "shape does not take the fused MFMA path"
     dx = torch.empty(B, T, F, Cin, device=dy.device)
     part = torch.empty(rows, 2, Cin, device=dy.device)
+    if scale is None:
+        scale = gamma * rstd
+        shift = beta - mean * scale
     check(lib().sed_conv3x3_dgrad_bnred(ptr(_f32c(dy)), ptr(_f32c(wd)), ptr(dx), ptr(part), ptr(_f32c(pooled)), ptr(gamma), ptr(beta),
                                         ptr(_f32c(y_below)), ptr(mean), ptr(rstd), drop_p, pool_f, pool_t, y_below.shape[2],
                                         y_below.shape[1], B, Cc, F, T, Cin, stream_ptr()), "conv3x3_dgrad_bnred")
     sum_g, sum_gx = torch.empty(Cin, device=dy.device), torch.empty(Cin, device=dy.device)
-    check(lib().sed_bn_bwd_finalize(ptr(part), rows, Cin, ptr(sum_g), ptr(sum_gx), None, None, stream_ptr()), "bn_bwd_finalize")
+    # (a stored conv output below: the small-|gamma| channels are finished from it by the finalising kernel)
+    check(lib().sed_bn_bwd_finalize_small_gamma(ptr(part), rows, Cin, ptr(sum_g), ptr(sum_gx), None, None, ptr(dx), ptr(pooled),
+                                                ptr(y_below), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+                                                B, y_below.shape[1], y_below.shape[2], pool_f, pool_t, drop_p, stream_ptr()),
+          "bn_bwd_finalize_small_gamma")
     return dx, sum_g, sum_gx
 
 

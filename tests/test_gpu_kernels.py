@@ -246,6 +246,12 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
     gamma[3], beta[3] = 0.0, 0.5
     gamma[77], beta[77] = 0.0, -0.2
     gamma[100] = -0.7                                                            # a negative scale flips the arg-max
+    # |gamma| << |beta| (round-3 advisor): xhat = (z - beta)/gamma would lose eps |beta/gamma| — these channels must take xhat
+    # from the conv output (window searched like the forward does); their sums are held to the SAME tolerance as the others
+    gamma[8], beta[8] = 1e-3, 0.5
+    gamma[9], beta[9] = -1e-5, 0.4
+    gamma[10], beta[10] = 1e-5, 0.6
+    gamma[11], beta[11] = 0.02, 0.9                                              # just above the 1/64 switch: the fast path, error bound 4e-6
     gamma, beta = gamma.cuda(), beta.cuda()
     n = B * Ty * Fy
     flat = yb.reshape(-1, C)
@@ -260,7 +266,7 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
     _, wd = ops.conv3x3_pack(w)
     dx_ref, _ = ops.conv3x3_fwd(dy, wd, None, False, want_stats=False)
     _, dgamma_ref, dbeta_ref, _ = ops.bn_relu_pool_drop_bwd(yb, dx_ref, scale, shift, mean, rstd, pf, pt, drop_p=p, seed=seed)
-    dx, sum_g, sum_gx = ops.conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p)
+    dx, sum_g, sum_gx = ops.conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p, scale=scale, shift=shift)
     assert torch.equal(dx, dx_ref)
     keep_scale = 1.0 / (1.0 - p)
     mag = float((dx_ref.abs() * keep_scale).sum(dim=(0, 1, 2)).max())        # an upper bound of sum |g| per channel
@@ -268,6 +274,9 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
     close(sum_gx, dgamma_ref, atol=6e-6 * mag, rtol=1e-4)
     assert float(sum_g[77].abs()) == 0.0 and float(sum_gx[77].abs()) == 0.0      # gamma 0, beta < 0: the gate is shut everywhere
     assert float(sum_gx[3].abs()) > 0.0
+    for c in (8, 9, 10, 11):                                                     # the small-gamma channels, individually
+        assert abs(float(sum_gx[c] - dgamma_ref[c])) <= 6e-6 * mag + 1e-4 * abs(float(dgamma_ref[c])), (c, float(sum_gx[c]), float(dgamma_ref[c]))
+        assert float(sum_gx[c].abs()) > 0.0
 
 
 @pytest.mark.parametrize("B,Ty,Fy,C,pf,pt,p", [(3, 16, 40, 128, 1, 2, 0.5), (2, 12, 40, 128, 1, 2, 0.0), (2, 9, 40, 128, 1, 2, 0.5),
@@ -284,6 +293,9 @@ def test_bn_backward_sums_of_the_gru_feeding_block_from_its_pooled_output(ops, B
     gamma[3], beta[3] = 0.0, 0.5
     gamma[17], beta[17] = 0.0, -0.2
     gamma[20] = -0.7
+    gamma[8], beta[8] = 1e-3, 0.5                                                # |gamma| << |beta|: xhat from the conv output (see above)
+    gamma[9], beta[9] = -1e-5, 0.4
+    gamma[10], beta[10] = 1e-5, 0.6
     gamma, beta = gamma.cuda(), beta.cuda()
     flat = yb.reshape(-1, C)
     part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).reshape(1, 2, C).contiguous()
@@ -292,12 +304,14 @@ def test_bn_backward_sums_of_the_gru_feeding_block_from_its_pooled_output(ops, B
     pooled = ops.bn_relu_pool_drop_fwd(yb, scale, shift, pf, pt, out_tcf=True, drop_p=p, seed=seed)       # [B,Tp,C,Fp]
     dout = (torch.randn(pooled.shape, generator=gen) * 0.1).cuda()
     _, dgamma_ref, dbeta_ref, _ = ops.bn_relu_pool_drop_bwd(yb, dout, scale, shift, mean, rstd, pf, pt, out_tcf=True, drop_p=p, seed=seed)
-    sum_g, sum_gx = ops.bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p)
+    sum_g, sum_gx = ops.bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p, scale=scale, shift=shift)
     mag = float((dout.abs() / (1.0 - p)).sum(dim=(0, 1, 3)).max())
     close(sum_g, dbeta_ref, atol=2e-6 * mag, rtol=1e-4)
     close(sum_gx, dgamma_ref, atol=6e-6 * mag, rtol=1e-4)
     assert float(sum_g[17].abs()) == 0.0 and float(sum_gx[17].abs()) == 0.0
     assert float(sum_gx[3].abs()) > 0.0
+    for c in (8, 9, 10):
+        assert abs(float(sum_gx[c] - dgamma_ref[c])) <= 6e-6 * mag + 1e-4 * abs(float(dgamma_ref[c])), (c, float(sum_gx[c]), float(dgamma_ref[c]))
 
 
 @pytest.mark.parametrize("B,F,T,p,cin", [(3, 40, 32, 0.5, 1), (2, 40, 20, 0.0, 1), (1, 40, 36, 0.5, 1), (2, 24, 12, 0.3, 1), (2, 128, 16, 0.5, 1),

@@ -225,6 +225,47 @@ def _oracle_vs_hip(sed, ref, m, x, y, loss="bce", atol=1e-3):
         _cmp(torch.sigmoid(m(x.cuda())), torch.sigmoid(ref(x)), atol=atol)
 
 
+@pytest.mark.parametrize("cin", [1, 2, 4])
+def test_batchnorm_channels_with_a_tiny_gamma_keep_exact_gradients(sed, cin):
+    """round-3 advisor: the fused BatchNorm-backward sums recover xhat = (z - beta)/gamma from a block's pooled output, which loses
+    eps |beta/gamma| when |gamma| << |beta| (z nearly constant) and does not exist for gamma == 0.  Such channels now take xhat
+    from where it is exact — the stored conv output (sed_bn_bwd_finalize_small_gamma for blocks below the top, the cold loop of
+    sed_bn_bwd_reduce_pooled for the top block) or, for the recomputed first block, its own tap sums (conv1_wgrad_assemble_k).
+    Full-width net (C = 128: every fused path is taken), channels with gamma = 1e-3, -1e-4, 1e-5 and 0 at beta = 0.5 / 0.3 in
+    EVERY block, against the oracle routed with the plan's decisions; dgamma of exactly those channels to 2e-4 relative."""
+    from oracle import crnn_ref
+    from test_gpu_sweep import hip_routes
+    torch.manual_seed(31 + cin)
+    kw = dict(conv_channels=128, dropout=0.0, in_channels=cin, n_mels=40, gru_hidden=16)
+    ref = crnn_ref.SedNetRef(**kw)
+    small = {3: (1e-3, 0.5), 5: (-1e-4, 0.5), 7: (0.0, 0.3), 9: (1e-5, 0.5), 64: (2e-3, -0.4)}
+    with torch.no_grad():
+        for bn in ref.bns:
+            for c, (gm, bt) in small.items():
+                bn.weight[c], bn.bias[c] = gm, bt
+    m = sed.TimePooledCRNN(**kw)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    x, y = crnn_ref.synthetic_batch(4, cin, 40, 64, 8, seed=17)
+    out = m(x.cuda())
+    sed.BCEWithLogitsLoss()(out, y.cuda()).backward()
+    ref.train()
+    audit = []
+    out_r = crnn_ref.forward_routed(ref, x, hip_routes(m), audit=audit)
+    crnn_ref.bce_logits(out_r, y).backward()
+    _cmp(torch.sigmoid(out), torch.sigmoid(out_r), atol=1e-4)
+    rg = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        g = rg[k].grad
+        _cmp(p.grad, g, atol=1e-4 + 1e-4 * float(g.abs().max()), rtol=1e-2, msg=k)
+    for l in range(3):
+        gh, gr = m.bns[l].weight.grad.cpu().double(), ref.bns[l].weight.grad.double()
+        scale = float(gr.abs().max())
+        for c in small:
+            assert abs(float(gh[c] - gr[c])) <= 2e-4 * abs(float(gr[c])) + 2e-6 * scale, (l, c, float(gh[c]), float(gr[c]))
+        assert float(gr[3].abs()) > 0                      # the channels are live (their gradient is not trivially 0)
+
+
 @pytest.mark.parametrize("cin,mel,T,H,C", [(2, 40, 32, 128, 128), (4, 128, 16, 64, 32), (1, 40, 64, 32, 16), (4, 128, 16, 256, 128)])
 def test_multichannel_configs_vs_oracle(sed, cin, mel, T, H, C):
     """binaural / 4-channel / 128-mel shapes of BASELINE configs 3 and 5 at sizes the oracle runs in seconds"""
