@@ -423,31 +423,39 @@ __global__ __launch_bounds__(256) void conv1_gram_finalize_k(const float* __rest
 
 // ── input moments for 3 or 4 input channels (config 5: 4-channel input) ──
 // conv1_gram_k keeps all NK + NK(NK+1)/2 accumulators of a thread in registers: 54 at one channel, 189 at two, 702 at four.
-// Here the second-moment matrix is cut into row blocks of C1_KB taps (blockIdx.y): a thread accumulates S1 of its C1_KB taps and
-// their products with ALL NK taps (the full rows; the finalisation reads the upper triangle), C1_KB * (NK + 1) <= 148 registers.
-// Every tap value read from LDS feeds C1_KB FMAs.  Partials [nblk][NKB][C1_KB][NK + 1] fp32, summed in fp64 in a fixed order.
-#define C1_KB 4
+// (Round 3 cut the matrix into row blocks of 4 taps, 148 accumulators per thread: LDS-bound, 1.39 ms at config 5; superseded.)
+#define C1_MM_BLOCKS 1024     // workgroups of conv1_moments_mfma_k (4 per CU: 21 KB of LDS each at 128 mel bins x 4 channels)
+// ── the moments of 3 and 4 input channels as a Gram matrix on the matrix cores (round 4) ──
+// S1 and G are V^T V for V = [positions x (9 CIN shifted inputs, 1)]: a rank-4-update per instruction with
+// v_mfma_f32_16x16x4_f32.  The NK + 1 features (the constant 1 gives S1 as the last column) are padded to NT = 2 or 3 tiles of 16;
+// lane l of a wave holds feature 16 t + (l & 15) of position (l >> 4) of the current group of four consecutive mel positions —
+// one ds_read_b32 per feature tile from the halo tile (per-lane offsets, a constant-1 and a zero word for the padding) — and
+// the NT (NT + 1) / 2 products of the upper triangle take these registers as A and B operands alike: 3 LDS reads per 6 MFMAs
+// where round 3's vector kernel read ~24 values per position and was LDS-bound (1.39 ms at config 5; this kernel: 0.33 ms).
+// Partials [workgroup][tile pair][256] fp32 (a wave sums 2048 positions at config 5), summed in fp64 in a fixed order.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int CIN>
-__global__ __launch_bounds__(256) void conv1_moments_k(const float* __restrict__ x, float* __restrict__ partials, int B, int F, int T) {
-    constexpr int NK = 9 * CIN, NKB = (NK + C1_KB - 1) / C1_KB;
+__global__ __launch_bounds__(256) void conv1_moments_mfma_k(const float* __restrict__ x, float* __restrict__ partials, int B, int F, int T) {
+    constexpr int NK = 9 * CIN, NT = (NK + 1 + 15) / 16, NP = NT * (NT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int F2 = F + 2;
-    float* halo = smem;                                       // [(GT+2)][F2][CIN]
-    const int tid = threadIdx.x, kb = blockIdx.y, k0 = kb * C1_KB;
-    const int tblocks = (T + C1_GT - 1) / C1_GT, ntiles = B * tblocks;
-    // LDS offsets of this row block's own taps (k = tap * CIN + ci, tap = kh * 3 + kw), relative to a position's halo origin
-    int aoff[C1_KB];
-#pragma unroll
-    for (int a = 0; a < C1_KB; ++a) {
-        const int k = (k0 + a < NK) ? k0 + a : NK - 1, tap = k / CIN, ci = k - tap * CIN, kh = tap / 3, kw = tap - kh * 3;
-        aoff[a] = (kw * F2 + kh) * CIN + ci;
-    }
-    float acc[C1_KB][NK + 1];
-#pragma unroll
-    for (int a = 0; a < C1_KB; ++a)
-#pragma unroll
-        for (int i = 0; i <= NK; ++i) acc[a][i] = 0.f;
     const int hn = (C1_GT + 2) * F2 * CIN;
+    float* halo = smem;                                       // [(GT+2)][F2][CIN], then {1.0f, 0.0f}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 15, kq = lane >> 4;
+    const int tblocks = (T + C1_GT - 1) / C1_GT, ntiles = B * tblocks;
+    int off[NT];
+    bool real[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int fi = 16 * t + m;
+        real[t] = fi < NK;
+        const int k = real[t] ? fi : 0, tap = k / CIN, ci = k - tap * CIN, kh = tap / 3, kw = tap - kh * 3;
+        off[t] = real[t] ? (kw * F2 + kh) * CIN + ci + kq * CIN : hn + (fi == NK ? 0 : 1);
+    }
+    f32x4_t acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) { halo[hn] = 1.f; halo[hn + 1] = 0.f; }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / tblocks, t0 = (tile - b * tblocks) * C1_GT;
         __syncthreads();
@@ -459,58 +467,49 @@ __global__ __launch_bounds__(256) void conv1_moments_k(const float* __restrict__
             halo[(tt * F2 + ff) * CIN + ci] = v;
         }
         __syncthreads();
-        for (int q = tid; q < C1_GT * F; q += 256) {
-            const int tl = q / F, f = q - tl * F;
-            if (t0 + tl >= T) continue;
-            const float* hp = halo + (tl * F2 + f) * CIN;
-            float va[C1_KB];
+        for (int row = wave; row < C1_GT && t0 + row < T; row += 4) {
+            for (int f0 = 0; f0 < F; f0 += 4) {
+                const int base = (row * F2 + f0) * CIN;
+                const bool live = f0 + kq < F;                 // a ragged last group: positions beyond the mel axis contribute nothing
+                float a[NT];
 #pragma unroll
-            for (int a = 0; a < C1_KB; ++a) { va[a] = hp[aoff[a]]; acc[a][0] += va[a]; }
-            // only the columns k2 >= k0 are kept (upper triangle): the block-uniform test skips the others' FMAs
+                for (int t = 0; t < NT; ++t) {
+                    const float v = halo[real[t] ? base + off[t] : off[t]];
+                    a[t] = live ? v : 0.f;
+                }
+                int q = 0;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) {
-                        const int k2 = (kh * 3 + kw) * CIN + ci;
-                        if (k2 >= k0) {
-                            const float v2 = hp[(kw * F2 + kh) * CIN + ci];
-#pragma unroll
-                            for (int a = 0; a < C1_KB; ++a) acc[a][1 + k2] += va[a] * v2;
-                        }
-                    }
+                    for (int tb = ta; tb < NT; ++tb, ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], a[tb], acc[q], 0, 0, 0);
+            }
         }
     }
     __syncthreads();
-    float* red = smem;                                         // [4] per value
-    const int lane = tid & 63, wave = tid >> 6;
-    float* dst = partials + ((size_t)blockIdx.x * NKB + kb) * C1_KB * (NK + 1);
+    float* red = smem;                                        // [4 waves][NP][256]
 #pragma unroll
-    for (int a = 0; a < C1_KB; ++a)
-#pragma unroll
-        for (int i = 0; i <= NK; ++i) {
-            const float sum = wave_sum(acc[a][i]);
-            if (lane == 0) red[(a * (NK + 1) + i) * 4 + wave] = sum;
-        }
+    for (int q = 0; q < NP; ++q) *(f32x4_t*)(red + ((wave * NP + q) * 64 + lane) * 4) = acc[q];
     __syncthreads();
-    for (int i = tid; i < C1_KB * (NK + 1); i += 256)
-        dst[i] = (red[i * 4] + red[i * 4 + 1]) + (red[i * 4 + 2] + red[i * 4 + 3]);
+    float* dst = partials + (size_t)blockIdx.x * NP * 256;
+    for (int i = tid; i < NP * 256; i += 256)
+        dst[i] = (red[i] + red[NP * 256 + i]) + (red[2 * NP * 256 + i] + red[3 * NP * 256 + i]);
 }
 
-// moments in fp64, packed like conv1_gram_k's (S1, then the upper triangle row by row): one workgroup per tap row, 64 lanes
-// over the partial rows of each entry
+// fp64 sums of the partials in workgroup order -> the packed moment vector (S1, then the upper triangle row by row).  Element
+// (row r, column c) of a 16 x 16 accumulator tile lies in lane 16 (r / 4) + c, register r % 4.
 template <int CIN>
-__global__ __launch_bounds__(64) void conv1_moments_sum_k(const float* __restrict__ partials, int nblk, double* __restrict__ gram_out) {
-    constexpr int NK = 9 * CIN, NKB = (NK + C1_KB - 1) / C1_KB, ROW = NK + 1;
-    const int k = blockIdx.x, kb = k / C1_KB, a = k - kb * C1_KB, lane = threadIdx.x;
-    for (int i = 0; i < ROW; ++i) {
-        if (i > 0 && i - 1 < k) continue;                      // lower triangle: not kept
-        double sum = 0.0;
-        for (int r = lane; r < nblk; r += 64) sum += (double)partials[(((size_t)r * NKB + kb) * C1_KB + a) * ROW + i];
-        sum = wave_sum_d(sum);
-        if (lane == 0) gram_out[i == 0 ? k : NK + k * NK - (k * (k - 1)) / 2 + (i - 1 - k)] = sum;
-    }
+__global__ __launch_bounds__(64) void conv1_moments_mfma_sum_k(const float* __restrict__ partials, int nblk, double* __restrict__ gram_out) {
+    constexpr int NK = 9 * CIN, NT = (NK + 1 + 15) / 16, NP = NT * (NT + 1) / 2;
+    const int k = blockIdx.x, k2 = blockIdx.y, lane = threadIdx.x;     // one wave per entry (k, k2) of the upper triangle;
+    if (k2 < k || (k2 == k && k == NK)) return;                          // column NK = the constant-1 feature = S1
+    const int ta = k >> 4, tb = k2 >> 4, r = k & 15, c = k2 & 15;
+    const int q = ta * NT - (ta * (ta - 1)) / 2 + (tb - ta);
+    const int e = (q * 64 + 16 * (r >> 2) + c) * 4 + (r & 3);
+    double sum = 0.0;
+    for (int i = lane; i < nblk; i += 64) sum += (double)partials[(size_t)i * NP * 256 + e];
+    sum = wave_sum_d(sum);
+    if (lane == 0) gram_out[k2 == NK ? k : NK + k * NK - (k * (k - 1)) / 2 + (k2 - k)] = sum;
 }
 
 // the statistics row (sum y, sum y^2 per channel) from the moments: fp64 quadratic form
@@ -518,20 +517,25 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv1_moments_stat_k(const double* __restrict__ G, const float* __restrict__ wp,
                                                             const float* __restrict__ bias, double count, int C, float* __restrict__ stat) {
     constexpr int NK = 9 * CIN;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per channel, lanes over the rows k
     if (c >= C) return;
     const double b = bias ? (double)bias[c] : 0.0;
     double ws1 = 0.0, q = 0.0;
-    for (int k = 0; k < NK; ++k) {
+    if (lane < NK) {
+        const int k = lane;
         const double wk = (double)wp[((size_t)(k / CIN) * C + c) * CIN + (k % CIN)];
-        ws1 += wk * G[k];
+        ws1 = wk * G[k];
         for (int k2 = k; k2 < NK; ++k2) {
             const double wk2 = (double)wp[((size_t)(k2 / CIN) * C + c) * CIN + (k2 % CIN)];
             q += (k2 == k ? 1.0 : 2.0) * wk * wk2 * G[NK + k * NK - (k * (k - 1)) / 2 + (k2 - k)];
         }
     }
-    stat[c] = (float)(count * b + ws1);
-    stat[C + c] = (float)(q + 2.0 * b * ws1 + count * b * b);
+    ws1 = wave_sum_d(ws1);
+    q = wave_sum_d(q);
+    if (lane == 0) {
+        stat[c] = (float)(count * b + ws1);
+        stat[C + c] = (float)(q + 2.0 * b * ws1 + count * b * b);
+    }
 }
 
 // ── backward of the recomputed block WITHOUT recomputing it (round 3) ──
@@ -788,7 +792,10 @@ static int c1_launch(const float* x, const float* wp, const float* bias, const f
 
 extern "C" size_t sed_conv1_stats_workspace_bytes(int B, int Cin, int T) {
     const int nk = 9 * Cin;
-    if (Cin > 2) return (size_t)256 * ((nk + C1_KB - 1) / C1_KB) * C1_KB * (nk + 1) * sizeof(float) + (size_t)(nk + nk * (nk + 1) / 2) * sizeof(double);
+    if (Cin > 2) {      // the MFMA Gram kernel: up to 1024 workgroups x (tile pairs) x 256 floats, + the fp64 moment vector
+        const int nt = (nk + 1 + 15) / 16, np = nt * (nt + 1) / 2;
+        return (size_t)C1_MM_BLOCKS * np * 256 * sizeof(float) + (size_t)(nk + nk * (nk + 1) / 2) * sizeof(double);
+    }
     return (size_t)256 * (nk + nk * (nk + 1) / 2) * sizeof(float);      // at most 256 partial rows (one per workgroup)
 }
 
@@ -799,21 +806,21 @@ extern "C" int sed_conv1_stats(const float* x, const float* wp, const float* bia
     hipStream_t s = as_stream(stream);
     SedProfScope prof(SED_K_CONV_SMALL_FWD, s, 4.0 * B * Cin * (double)F * T);
     if (Cin > 2) {
-        const int nk = 9 * Cin, nkb = (nk + C1_KB - 1) / C1_KB;
+        const int nk = 9 * Cin, nt = (nk + 1 + 15) / 16, np = nt * (nt + 1) / 2;
         int nb = B * ((T + C1_GT - 1) / C1_GT);
-        if (nb > 256) nb = 256;
-        size_t lds = (size_t)(C1_GT + 2) * (F + 2) * Cin * sizeof(float), red = (size_t)C1_KB * (nk + 1) * 4 * sizeof(float);
+        if (nb > C1_MM_BLOCKS) nb = C1_MM_BLOCKS;
+        size_t lds = ((size_t)(C1_GT + 2) * (F + 2) * Cin + 4) * sizeof(float), red = (size_t)4 * np * 256 * sizeof(float);
         if (red > lds) lds = red;
         SED_REQUIRE(lds <= 150 * 1024, "conv1_stats: F=%d Cin=%d needs %zu B of LDS", F, Cin, lds);
         const double cnt = (double)B * T * F;
         // the fp64 moments go to the caller's array, or behind the partial rows in the workspace when the caller does not want them
-        double* G = gram_out ? gram_out : (double*)((float*)workspace + (size_t)256 * nkb * C1_KB * (nk + 1));
+        double* G = gram_out ? gram_out : (double*)((float*)workspace + (size_t)C1_MM_BLOCKS * np * 256);
 #define C1_MOM(CIN_)                                                                                                              \
     do {                                                                                                                          \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_moments_k<CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        conv1_moments_k<CIN_><<<dim3(nb, nkb), 256, lds, s>>>(x, (float*)workspace, B, F, T);                                       \
-        conv1_moments_sum_k<CIN_><<<nk, 64, 0, s>>>((const float*)workspace, nb, G);                                               \
-        conv1_moments_stat_k<CIN_><<<cdiv(C, 256), 256, 0, s>>>(G, wp, bias, cnt, C, stat_partials);                               \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_moments_mfma_k<CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        conv1_moments_mfma_k<CIN_><<<nb, 256, lds, s>>>(x, (float*)workspace, B, F, T);                                             \
+        conv1_moments_mfma_sum_k<CIN_><<<dim3(nk + 1, nk + 1), 64, 0, s>>>((const float*)workspace, nb, G);                       \
+        conv1_moments_stat_k<CIN_><<<cdiv(C, 4), 256, 0, s>>>(G, wp, bias, cnt, C, stat_partials);                                 \
     } while (0)
         if (Cin == 3) C1_MOM(3); else C1_MOM(4);
 #undef C1_MOM

@@ -35,13 +35,19 @@ __global__ void gru_pack_whh_t_k(const float* __restrict__ w0, const float* __re
 
 constexpr int gru_nt(int hreg) { return hreg > 0 ? ((3 * hreg + 63) / 64) * 64 : 1024; }
 
-template <int HREG, int GRU_BT>
-__global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
+// Where a thread's gate row of W_hh lives.  HTOT == HREG: all of it in registers (H <= 128).  HREG == 0: all of it streamed
+// from L2 every step (any H).  Otherwise (round 4, H = 256): the first HREG weights in registers, the next HLDS in LDS (loaded
+// once; [j][3H], a thread reads its own column: conflict-free), the remaining HTOT - HREG - HLDS streamed.  At H = 256 the
+// matrix is 786 KB per direction — five times the LDS of a CU — and a step that streams all of it is bound by the CU's L2 port
+// (64 B/clk: 5.1 us); with 96 + 48 of 256 weights on chip 44 % is streamed.
+template <int HREG, int GRU_BT, int HTOT = HREG, int HLDS = 0>
+__global__ __launch_bounds__(gru_nt(HTOT)) void gru_seq_fwd_k(
     const float* __restrict__ gi, const float* __restrict__ wt, const float* __restrict__ bhh0,
     const float* __restrict__ bhh1, float* __restrict__ out, float* __restrict__ saved, int B, int T, int H) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* h_s = smem;                    // [BT][H]
     float* gh_s = smem + GRU_BT * H;      // [BT][3H]
+    float* w_l = smem + GRU_BT * 4 * H;   // [HLDS][3H] (hybrid only)
     const int g = threadIdx.x;
     const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BT;
     const int H3 = 3 * H;
@@ -49,11 +55,15 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
     const float* bhh = dir ? bhh1 : bhh0;
     const bool row = g < H3;
     const bool gate = g < H;
+    constexpr bool HYB = HTOT != HREG && HREG > 0;
 
     float wreg[HREG > 0 ? HREG : 1];
     if (HREG > 0 && row) {
 #pragma unroll
         for (int k = 0; k < HREG; ++k) wreg[k] = wtd[(size_t)k * H3 + g];
+    }
+    if (HYB && row) {
+        for (int j = 0; j < HLDS; ++j) w_l[j * H3 + g] = wtd[(size_t)(HREG + j) * H3 + g];
     }
     const float bias = row ? bhh[g] : 0.f;
     for (int i = g; i < GRU_BT * H; i += blockDim.x) h_s[i] = 0.f;
@@ -91,8 +101,20 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
                         acc[b] += wreg[k] * hv[0] + wreg[k + 1] * hv[1] + wreg[k + 2] * hv[2] + wreg[k + 3] * hv[3];
                     }
                 }
-            } else {
-                for (int k = 0; k < H; k += 4) {
+            }
+            if (HYB) {
+#pragma unroll 4
+                for (int j = 0; j < HLDS; j += 4) {
+                    const float w0 = w_l[j * H3 + g], w1 = w_l[(j + 1) * H3 + g], w2 = w_l[(j + 2) * H3 + g], w3 = w_l[(j + 3) * H3 + g];
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 hv = *(const f32x4*)(h_s + b * H + HREG + j);
+                        acc[b] += w0 * hv[0] + w1 * hv[1] + w2 * hv[2] + w3 * hv[3];
+                    }
+                }
+            }
+            if (HREG == 0 || HYB) {
+                for (int k = HYB ? HREG + HLDS : 0; k < H; k += 4) {
                     float w0 = wtd[(size_t)k * H3 + g], w1 = wtd[(size_t)(k + 1) * H3 + g];
                     float w2 = wtd[(size_t)(k + 2) * H3 + g], w3 = wtd[(size_t)(k + 3) * H3 + g];
 #pragma unroll
@@ -139,8 +161,8 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_fwd_k(
     }
 }
 
-template <int HREG, int GRU_BT>
-__global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
+template <int HREG, int GRU_BT, int HTOT = HREG, int HLDS = 0>
+__global__ __launch_bounds__(gru_nt(HTOT)) void gru_seq_bwd_k(
     const float* __restrict__ dout, const float* __restrict__ saved, const float* __restrict__ whh0,
     const float* __restrict__ whh1, float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ bpart,
     int B, int T, int H) {
@@ -148,17 +170,22 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
     const int H3 = 3 * H;
     float* dgh_s = smem;                         // [BT][3H]
     float* part_s = smem + GRU_BT * H3;          // [3][BT][H]
+    float* w_l = smem + GRU_BT * 2 * H3;         // [HLDS][3H] (hybrid only)
     const int g = threadIdx.x;
     const int dir = blockIdx.y, b0 = blockIdx.x * GRU_BT;
     const float* whh = dir ? whh1 : whh0;
     const bool row = g < H3;
     const bool gate = g < H;
     const int p = g / H, k = g - p * H;          // thread (p,k): column k of gate block p
+    constexpr bool HYB = HTOT != HREG && HREG > 0;
 
     float wreg[HREG > 0 ? HREG : 1];
     if (HREG > 0 && row) {
 #pragma unroll
         for (int j = 0; j < HREG; ++j) wreg[j] = whh[((size_t)p * H + j) * H + k];
+    }
+    if (HYB && row) {
+        for (int j = 0; j < HLDS; ++j) w_l[j * H3 + g] = whh[((size_t)p * H + HREG + j) * H + k];
     }
     for (int i = g; i < 3 * GRU_BT * H; i += blockDim.x) part_s[i] = 0.f;
     float dhc[GRU_BT];                           // direct part z*dh carried by the gate thread
@@ -181,7 +208,7 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
         }
     };
     // two steps ahead, as in the forward kernel (one step ahead where the 1024-thread variant has no registers to spare)
-    constexpr bool AHEAD2 = !(HREG == 0 && GRU_BT == 4);
+    constexpr bool AHEAD2 = !(HREG == 0 && GRU_BT == 4) && !HYB;      // (hybrid: the register budget goes to the weights)
     fetch_sv(0, cs);
     if (AHEAD2) fetch_sv(1, ns);
     for (int s = 0; s < T; ++s) {
@@ -229,8 +256,20 @@ __global__ __launch_bounds__(gru_nt(HREG)) void gru_seq_bwd_k(
                         acc[b] += wreg[j] * dv[0] + wreg[j + 1] * dv[1] + wreg[j + 2] * dv[2] + wreg[j + 3] * dv[3];
                     }
                 }
-            } else {
-                for (int j = 0; j < H; j += 4) {
+            }
+            if (HYB) {
+#pragma unroll 4
+                for (int j = 0; j < HLDS; j += 4) {
+                    const float w0 = w_l[j * H3 + g], w1 = w_l[(j + 1) * H3 + g], w2 = w_l[(j + 2) * H3 + g], w3 = w_l[(j + 3) * H3 + g];
+#pragma unroll
+                    for (int b = 0; b < GRU_BT; ++b) {
+                        f32x4 dv = *(const f32x4*)(dgh_s + b * H3 + p * H + HREG + j);
+                        acc[b] += w0 * dv[0] + w1 * dv[1] + w2 * dv[2] + w3 * dv[3];
+                    }
+                }
+            }
+            if (HREG == 0 || HYB) {
+                for (int j = HYB ? HREG + HLDS : 0; j < H; j += 4) {
                     const float* wp = whh + ((size_t)p * H + j) * H + k;
                     float w0 = wp[0], w1 = wp[H], w2 = wp[2 * H], w3 = wp[3 * H];
 #pragma unroll
@@ -272,6 +311,10 @@ __global__ void gru_bias_grad_k(const float* __restrict__ bpart, int nblk, int H
 }
 
 static int gru_threads(int H) { return ((3 * H + 63) / 64) * 64; }
+// H = 256, one sample per workgroup: weights 0..GRU_HR-1 of a gate row in registers, the next GRU_HL in LDS, the rest streamed
+#define GRU_HR 96
+#define GRU_HL 48
+#define GRU_HR_FWD 116     // the forward kernel has 20 more registers to spare (148 of the 168 a 768-thread workgroup may use at HR = 96)
 
 extern "C" size_t sed_gru_seq_workspace_bytes(int H) { return (size_t)2 * 3 * H * H * sizeof(float); }
 
@@ -288,6 +331,10 @@ extern "C" size_t sed_gru_seq_workspace_bytes(int H) { return (size_t)2 * 3 * H 
         case 128:                                                                             \
             if (bt == 1) KERNEL<128, 1><<<grid, nt, lds, s>>>(__VA_ARGS__);                   \
             else KERNEL<128, 2><<<grid, nt, lds, s>>>(__VA_ARGS__);                           \
+            break;                                                                            \
+        case 256:                                                                             \
+            if (bt == 1) { hyb = 1; KERNEL<GRU_HRX, 1, 256, GRU_HL><<<grid, nt, lds + (size_t)GRU_HL * 768 * sizeof(float), s>>>(__VA_ARGS__); } \
+            else { GRU_BT3(0, KERNEL, __VA_ARGS__); }                                         \
             break;                                                                            \
         default: GRU_BT3(0, KERNEL, __VA_ARGS__); break;                                      \
     }
@@ -306,7 +353,13 @@ extern "C" int sed_gru_seq_fwd(const float* gi, const float* const* whh, const f
     int nt = gru_threads(H);
     size_t lds = (size_t)bt * 4 * H * sizeof(float);
     SedProfScope prof(SED_K_GRU_FWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
+    int hyb = 0;
+    if (H == 256 && bt == 1)
+        (void)hipFuncSetAttribute((const void*)gru_seq_fwd_k<GRU_HR_FWD, 1, 256, GRU_HL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define GRU_HRX GRU_HR_FWD
     GRU_DISPATCH(gru_seq_fwd_k, gi, wt, bhh[0], bhh[1], out, saved, B, T, H);
+#undef GRU_HRX
+    (void)hyb;
     SED_LAUNCH_CHECK("gru_seq_fwd");
     return 0;
 }
@@ -327,7 +380,13 @@ extern "C" int sed_gru_seq_bwd(const float* dout, const float* saved, const floa
     int nt = gru_threads(H);
     size_t lds = (size_t)bt * 6 * H * sizeof(float);
     SedProfScope prof(SED_K_GRU_BWD, s, 2.0 * 2 * B * (double)T * 3 * H * H);
+    int hyb = 0;
+    if (H == 256 && bt == 1)
+        (void)hipFuncSetAttribute((const void*)gru_seq_bwd_k<GRU_HR, 1, 256, GRU_HL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define GRU_HRX GRU_HR
     GRU_DISPATCH(gru_seq_bwd_k, dout, saved, whh[0], whh[1], dgi, dgh, bpart, B, T, H);
+#undef GRU_HRX
+    (void)hyb;
     SED_LAUNCH_CHECK("gru_seq_bwd");
     if (want_bias) {
         gru_bias_grad_k<<<cdiv(8 * H, 256), 256, 0, s>>>(bpart, cdiv(B, bt), H, dbih[0], dbih[1], dbhh[0], dbhh[1]);
