@@ -663,6 +663,121 @@ __global__ __launch_bounds__(256, CIN == 1 ? 4 : 2) void conv1_rgrad_k(
     }
 }
 
+// ── the same sums on the matrix cores (round 4; 3 and 4 input channels, C a multiple of 64) ──
+// R[k][c] = sum over pooled positions of g~[pos][c] * v_k(arg-max row of (pos, c)) is a product V^T G~ once the routed gradient
+// is split by the arg-max bit: one v_mfma_f32_32x32x2_f32 takes the two un-pooled time rows of a pooled position as its two k
+// indices — A[feature][row parity] = the shifted input at that row (one ds_read_b32 per lane from the halo tile; the constant-1
+// feature behind the taps gives sum g~ = partial value 0), B[row parity][channel] = g~ where the bit names that row, else 0.
+// Per pooled position: 2 feature tiles x 4 channel tiles = 8 MFMAs against ~80 vector instructions per channel quad in
+// conv1_rgrad_k<4>, whose 2.1 ms of vector work trailed the last weight gradient at config 5 (the fp32 MFMA shares the vector
+// ALU: a vector kernel beside it costs its own stand-alone time).  A wave owns one pooled row of the tile and all 128 channels of
+// a 64-channel group (blockIdx.y): 4 accumulator tiles, so that three waves per SIMD fit; the four waves of a workgroup are
+// summed through LDS, one tile per round.
+#define C1_RM_GT 8            // un-pooled time rows per tile: four pooled rows, one per wave
+#define C1_RM_CT 2            // 32-channel tiles per wave (blockIdx.y = a group of 64 channels): 4 accumulator tiles at 4 input channels
+#define C1_RM_D 8             // mel positions of gradient / pooled / bit loads in flight per lane
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1_rgrad_mfma_k(
+    const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ pooled,
+    const unsigned char* __restrict__ bits, float* __restrict__ partials, int B, int F, int T, int C, float inv_keep) {
+    constexpr int NK = 9 * CIN, NV = 1 + NK, NFT = (NV + 31) / 32, CT = C1_RM_CT, D = C1_RM_D;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int F2 = F + 2, Tp = T >> 1;
+    const int hn = (C1_RM_GT + 2) * F2 * CIN;
+    float* halo = smem;                                       // [(GT+2)][F2][CIN], then {1.0f, 0.0f}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, kk = lane >> 5;
+    const int tblocks = (T + C1_RM_GT - 1) / C1_RM_GT, ntiles = B * tblocks;
+    const int cg = blockIdx.y * (32 * CT);
+    int aoff[NFT];
+    bool areal[NFT];
+#pragma unroll
+    for (int ta = 0; ta < NFT; ++ta) {
+        const int fi = 32 * ta + i;
+        areal[ta] = fi < NK;
+        const int k = areal[ta] ? fi : 0, tap = k / CIN, ci = k - tap * CIN, kh = tap / 3, kw = tap - kh * 3;
+        aoff[ta] = areal[ta] ? ((kw + kk) * F2 + kh) * CIN + ci : hn + (fi == NK ? 0 : 1);
+    }
+    f32x16 acc[NFT][CT];
+#pragma unroll
+    for (int ta = 0; ta < NFT; ++ta)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[ta][ct][j] = 0.f;
+    if (tid == 0) { halo[hn] = 1.f; halo[hn + 1] = 0.f; }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tblocks, t0 = (tile - b * tblocks) * C1_RM_GT;
+        __syncthreads();
+        for (int j = tid; j < hn; j += 256) {                 // time fastest: contiguous in the NCHW input
+            int tt = j % (C1_RM_GT + 2), ff = (j / (C1_RM_GT + 2)) % F2, ci = j / ((C1_RM_GT + 2) * F2);
+            const int t = t0 + tt - 1, f = ff - 1;
+            float v = 0.f;
+            if (t >= 0 && t < T && f >= 0 && f < F) v = x[(((size_t)b * CIN + ci) * F + f) * T + t];
+            halo[(tt * F2 + ff) * CIN + ci] = v;
+        }
+        __syncthreads();
+        const int tp = (t0 >> 1) + wave;                       // this wave's pooled row
+        if (tp < Tp) {
+            const size_t prow = ((size_t)b * Tp + tp) * F;
+            const float* dp = dout + prow * C + cg + i;
+            const float* pp = pooled + prow * C + cg + i;
+            const unsigned char* bp = bits + prow * (C >> 2) + ((cg + i) >> 2);
+            const int rowbase = (2 * wave) * F2 * CIN;         // halo origin of un-pooled row 2 (tp - t0/2), mel 0 (tap (0,0) = one row / column up)
+            // the gradient, the pooled value and the bit byte of D mel positions are in flight per lane: an un-pipelined load per
+            // position made this loop a chain of HBM round trips (first version: 13 ms instead of 1)
+            float dv[D][CT], qv[D][CT];
+            unsigned bv8[D][CT];
+            auto load = [&](int slot, int f) {
+                const int fc = f < F ? f : F - 1;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    dv[slot][ct] = dp[(size_t)fc * C + ct * 32];
+                    qv[slot][ct] = pp[(size_t)fc * C + ct * 32];
+                    bv8[slot][ct] = bp[(size_t)fc * (C >> 2) + ct * 8];
+                }
+            };
+#pragma unroll
+            for (int sl = 0; sl < D; ++sl) load(sl, sl);
+            for (int f0 = 0; f0 < F; f0 += D) {
+#pragma unroll
+                for (int sl = 0; sl < D; ++sl) {
+                    const int f = f0 + sl;
+                    const int base = rowbase + (f < F ? f : F - 1) * CIN;
+                    float a[NFT];
+#pragma unroll
+                    for (int ta = 0; ta < NFT; ++ta) a[ta] = halo[areal[ta] ? base + aoff[ta] : aoff[ta]];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const float bv = (f < F && qv[sl][ct] > 0.f && (int)((bv8[sl][ct] >> (i & 3)) & 1u) == kk) ? dv[sl][ct] * inv_keep : 0.f;
+#pragma unroll
+                        for (int ta = 0; ta < NFT; ++ta)
+                            acc[ta][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], bv, acc[ta][ct], 0, 0, 0);
+                    }
+                    load(sl, f + D);
+                }
+            }
+        }
+    }
+    // four waves -> one partial row: a 32 x 32 tile per round through LDS (16 KB), fixed order
+    float* red = smem;                                        // [4 waves][32 rows][32 cols]
+#pragma unroll
+    for (int ta = 0; ta < NFT; ++ta)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[(wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * kk) * 32 + i] = acc[ta][ct][j];
+            __syncthreads();
+            for (int e = tid; e < 1024; e += 256) {
+                const int row = e >> 5, col = e & 31, fi = 32 * ta + row;
+                if (fi <= NK) {
+                    const float sum = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+                    partials[((size_t)blockIdx.x * C + cg + ct * 32 + col) * NV + (fi == NK ? 0 : 1 + fi)] = sum;
+                }
+            }
+        }
+}
+
 // index of G(k, k2), k <= k2, in the moment vector [S1 (NK) | upper triangle row by row] of conv1_gram_k
 __device__ __forceinline__ int c1_gidx(int k, int k2, int NK) { return NK + k * NK - (k * (k - 1)) / 2 + (k2 - k); }
 
@@ -957,20 +1072,35 @@ extern "C" int sed_conv1_bwd_wgrad(const float* x, const float* dout, const floa
     SedProfScope prof(SED_K_BN_BWD_APPLY, s, 2.0 * 4.0 * B * C * (double)(T / 2) * F);
     size_t lds = (size_t)(C1_TT + 2) * (F + 2) * Cin * sizeof(float);      // halo tile, or the one-value reduction buffer
     if (lds < (size_t)256 * 4 * sizeof(float)) lds = (size_t)256 * 4 * sizeof(float);
-    const int grid = c1_rgrad_rows(B, T);
+    int grid = c1_rgrad_rows(B, T);
     const float inv_keep = 1.f / (1.f - drop_p);
+    const size_t lds_m = ((size_t)(C1_RM_GT + 2) * (F + 2) * Cin + 4) * sizeof(float) > (size_t)4096 * sizeof(float)
+                             ? ((size_t)(C1_RM_GT + 2) * (F + 2) * Cin + 4) * sizeof(float) : (size_t)4096 * sizeof(float);
+    if (Cin >= 3 && C % (32 * C1_RM_CT) == 0 && lds_m <= 64 * 1024) {
+        // 3 / 4 input channels: the sums on the matrix cores (conv1_rgrad_mfma_k); one partial row per workgroup as before
+        int g2 = B * ((T + C1_RM_GT - 1) / C1_RM_GT);
+        if (g2 < grid) grid = g2;
+        if (Cin == 3) {
+            if (lds_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_mfma_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            conv1_rgrad_mfma_k<3><<<dim3(grid, C / (32 * C1_RM_CT)), 256, lds_m, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
+        } else {
+            if (lds_m > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_mfma_k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+            conv1_rgrad_mfma_k<4><<<dim3(grid, C / (32 * C1_RM_CT)), 256, lds_m, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);
+        }
+    } else {
 #define C1_RGRAD(CIN_)                                                                                                        \
     do {                                                                                                                      \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)conv1_rgrad_k<CIN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         conv1_rgrad_k<CIN_><<<grid, 256, lds, s>>>(x, dout, pooled, argmax_bits, (float*)workspace, B, F, T, C, inv_keep);    \
     } while (0)
-    switch (Cin) {
-        case 1: C1_RGRAD(1); break;
-        case 2: C1_RGRAD(2); break;
-        case 3: C1_RGRAD(3); break;
-        default: C1_RGRAD(4); break;
-    }
+        switch (Cin) {
+            case 1: C1_RGRAD(1); break;
+            case 2: C1_RGRAD(2); break;
+            case 3: C1_RGRAD(3); break;
+            default: C1_RGRAD(4); break;
+        }
 #undef C1_RGRAD
+    }
     SED_LAUNCH_CHECK("conv1_rgrad");
     conv1_wgrad_assemble_k<<<C, 256, 0, s>>>((const float*)workspace, grid, Cin, C, moments, wp, bias, mean, rstd, scale, sum_g, sum_gx,
                                            (double)B * T * F, dw_oihw, dbias, gamma, beta, dgamma);
