@@ -125,6 +125,24 @@ int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, f
                             const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                             const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                             int B, int C, int F, int T, int Cin, void* stream);
+/* ---- Winograd F(2x2, 3x3) form of the 128-input-channel convolutions (wino.hip; reference sed.py:88,107, the same nn.Conv2d) ----
+ * Exact-fp32 MFMA arithmetic on 16 transformed products per 2x2 output tile instead of 36 (2.25x fewer MFMAs); the transforms'
+ * coefficients are 0, +-1 and 1/2, the result differs from the direct kernels' by a few ulp of the accumulated magnitude.
+ * Shapes: Cin == 128, Cout % 64 == 0, F and T even, a tile-row patch that fits the LDS; sed_conv3x3_wino_rows() = the number of
+ * statistic / partial rows ([rows][2][Cout], as sed_conv3x3_fwd) or 0 when the shape is not taken.
+ * pack_weights: w [Cout][Cin][3][3] -> uf (forward) and ud (data gradient: flipped taps, channel roles swapped), each
+ * sed_conv3x3_wino_packed_floats() floats (16 Cin Cout transformed weights in MFMA fragment order + a zero tail the kernel reads
+ * its zero padding from); either may be NULL.
+ * wino_fwd = sed_conv3x3_fwd on channels-last x; wino_dgrad_bnred = sed_conv3x3_dgrad_bnred (same arguments and outputs). */
+int sed_conv3x3_wino_rows(int B, int Cin, int F, int T, int Cout);
+size_t sed_conv3x3_wino_packed_floats(int Cout, int Cin);
+int sed_conv3x3_wino_pack_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin, void* stream);
+int sed_conv3x3_wino_fwd(const float* x, const float* uf, const float* bias, float* y, float* stat_partials,
+                         int B, int Cin, int F, int T, int Cout, void* stream);
+int sed_conv3x3_wino_dgrad_bnred(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,
+                                 const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                                 const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                                 int B, int C, int F, int T, int Cin, void* stream);
 /* The same launch when the block below is the recomputed first block with Cin1 = 1 or 2 input channels and pool (1,2)
  * (sed.py:86-92, ch = 1 or 2): the epilogue also forms that block's weight-gradient sums — rg_partials [rows][Cin][1 + 9 Cin1]
  * = (sum g, R_k) per channel and workgroup, R_{(3kh+kw) Cin1 + ci} = sum g~ x[ci][f+kh-1][2t'+sel+kw-1] with sel the arg-max

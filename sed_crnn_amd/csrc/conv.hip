@@ -14,6 +14,7 @@
 // Both write per-block BatchNorm partial sums (sum, sum of squares) from the epilogue so the
 // conv output is not re-read for the statistics.
 #include "common.h"
+#include "conv_shared.h"
 #include <type_traits>
 
 #define CV_CIC 32   // input channels per LDS chunk
@@ -457,21 +458,6 @@ __global__ __launch_bounds__(256) void conv3x3_small_fwd_c_k(
 //     (sed_bn_bwd_finalize_small_gamma; a cold path inside a launch that exists anyway);
 //   * a recomputed first block: gamma == 0 only here; its own passes form sum g*xhat for every channel (conv1_wgrad_assemble_k
 //     exactly, from the R_k; the recomputing apply pass for gamma == 0).
-struct ConvBnRed {
-    const float* pooled;     // [B][T][F][Cout] forward output of the block whose BatchNorm is being differentiated
-    const float* gamma;      // [Cout]
-    const float* beta;       // [Cout]
-    const float* ybelow;     // != NULL: the block below stores its conv output — channels whose xhat cannot be recovered from the pooled
-    const float* mean;       // output (|gamma| < |beta| / 64) then contribute 0 here and are recomputed by sed_bn_bwd_finalize_small_gamma
-    const float* rstd;
-    float keep, inv_keep;    // 1 - p, 1 / (1 - p)
-    int pf, pt, Fy, Ty;      // pool and the extents of ybelow
-    // RG (the block below is the recomputed 1-channel first block, pool (1,2)): also its weight-gradient sums, see the kernel
-    const float* x1;         // the network input [B][RGC][Fy][Ty]
-    const unsigned char* bits;   // arg-max bits of the block below: [B][T][F][Cout/4] bytes, bit e = channel 4q+e took the second time row
-    float* rgp;              // out: [rows][Cout][1 + 9 RGC] = (sum g, R_k) per workgroup
-    float invXT;             // 1 / (2 TT + 2)
-};
 
 // EV (inference, sed.py:128-141 with optim=None): BatchNorm is folded into the packed weights and the bias on the host side of
 // the launch (running statistics are constants), and the epilogue applies ReLU + the (1,2) time pool before anything is

@@ -1,0 +1,426 @@
+// wino.hip — the 3x3 convolution of the 128-channel blocks as Winograd F(2x2, 3x3), exact-fp32 MFMA.
+//
+// Same operator as conv3x3_mfma_fwd2_k (conv.hip; reference sed.py:88,107 nn.Conv2d forward and, with flipped / transposed
+// weights, its data gradient), 2.25x fewer multiplications: a 2x2 output tile is computed from its 4x4 input patch d as
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A,
+// 16 products per input / output channel pair instead of 36.  On gfx950 the fp32 MFMA (v_mfma_f32_32x32x2_f32: 256 flop per
+// cycle and CU) is the ceiling of the direct kernel (0.87 of it reached), so the only way below it is fewer MFMAs.  The
+// transforms use the coefficients 0, +-1 (input, output) and 1, 1/2 (weights): in fp32 the result differs from the direct sum by
+// a few ulp of the accumulated magnitude (measured in tests/test_gpu_kernels.py next to the direct kernel's own error), far
+// inside the 1e-3 the north star asks of the outputs.
+//
+// GEMM view: 16 independent products M_k[tile][co] = sum_ci V_k[tile][ci] U_k[ci][co], k = (xi, nu) the component,
+// tile = a 2x2 output tile.  A workgroup owns 64 consecutive tiles of one sequence (tiles linearised over (time pair, mel pair):
+// any mel width fills the MFMA rows) x 64 output channels; wave xi holds the four components (xi, 0..3) of 2 x 2 MFMA tiles
+// (32 tiles x 32 channels each): 16 accumulators = 256 registers, ONE wave per SIMD.
+//   * input: the patch of the block's tile rows (2 TR + 2 time rows x F + 2 mel columns x 32 channels per slice) comes in by
+//     LDS-DMA (global_load_lds_dwordx4, no staging registers), double buffered, one barrier per 32-channel slice.  LDS image:
+//     8 positions per KiB, quad-major inside ([quad][position]): a wave's DMA covers 8 whole positions (coalesced), a lane's
+//     ds_read_b128 of (position, quad) is conflict-free over consecutive positions, and the k-group g of a step is an
+//     immediate offset.  Mel columns are stored even ones first, so that the tiles of a row are consecutive positions.
+//   * the input transform happens in registers on the way to the A operand: wave xi reads the two time rows of its row
+//     combination (B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3), 4 columns each, and forms the four column combinations:
+//     16 ds_read_b128 + 32 float4 additions per 64 MFMAs, shared by both channel tiles.
+//   * weights: U = G g G^T is formed by the packing launch in MFMA B-fragment order, [component][ci/32][ (ci%32)/8 ][co/32]
+//     [lane][4]; a wave streams its 4 components x 2 channel tiles from L2, the fragments of a component for the next
+//     step requested as soon as this step's MFMAs of that component have issued (rolling, 48 MFMAs ahead).
+//   * output transform: in registers along nu (4 -> 2), across the four waves (xi) through LDS, then the same row-wise
+//     epilogue as the direct kernel: 4 channels x 8 rows per store instruction, BatchNorm statistics (forward) or the
+//     BatchNorm-backward sums of the block below (data gradient, ConvBnRed) from the values in registers.
+// Fixed summation order: run-to-run identical results.
+#include "common.h"
+#include "conv_shared.h"
+#include <type_traits>
+
+#define WN_CIN 128          // input channels (the contraction): 4 slices of 32, 16 steps of 8 — fully unrolled
+#define WN_NHMAX 14         // KiB blocks of the patch per wave (56 KiB per buffer)
+
+typedef __attribute__((address_space(1))) const void* sed_gptr_t;
+typedef __attribute__((address_space(3))) void* sed_lptr_t;
+
+struct WinoGeo {
+    int Fw, Tw, ntile, nblk, TR, F2, H2, HR, nb8, ncoh, NH;
+    float invFw, invF2;
+    size_t lds;
+};
+
+// ───────────────────────── weight transform + packing ─────────────────────────
+// fragment order [co/64][component][ci/32][(ci%32)/8][(co%64)/32][lane = co%32 + 32 ((ci%8)/4)][ci%4]: everything a workgroup (one
+// channel half) streams is one contiguous 16 K 64 floats, and inside it every (component, step, channel tile) offset is a constant
+__host__ __device__ inline size_t wino_frag_index(int comp, int k, int n, int K, int N) {
+    const int cc = k >> 5, g = (k & 31) >> 3, h = (k & 7) >> 2, j = k & 3, coh = n >> 6, nt = (n >> 5) & 1, r = n & 31;
+    (void)N;
+    return (((((((size_t)coh * 16 + comp) * (K >> 5) + cc) * 4 + g) * 2 + nt) * 64) + r + 32 * h) * 4 + j;
+}
+#define WN_ZTAIL 256        // zero floats behind the packed weights: the source of the patch's zero padding (LDS-DMA cannot write a constant)
+// one thread per (co, ci): U = G g G^T for the forward (g[a][c] = w[co][ci][kh = c][kw = a]: a runs along time, c along mel) and for
+// the data gradient (contraction over co, g'[a][c] = w[co][ci][2 - c][2 - a])
+__global__ void conv_pack_wino_k(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < WN_ZTAIL) {
+        if (uf) uf[(size_t)16 * Cout * Cin + i] = 0.f;
+        if (ud) ud[(size_t)16 * Cout * Cin + i] = 0.f;
+    }
+    if (i >= Cout * Cin) return;
+    const int ci = i % Cin, co = i / Cin;
+    float g[3][3];                                   // [a = kw][c = kh]
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) g[kw][kh] = w[(size_t)i * 9 + kh * 3 + kw];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float* dst = pass ? ud : uf;
+        if (!dst) continue;
+        float t[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g0 = pass ? g[2][2 - c] : g[0][c], g1 = pass ? g[1][2 - c] : g[1][c], g2 = pass ? g[0][2 - c] : g[2][c];
+            t[0][c] = g0;
+            t[1][c] = 0.5f * (g0 + g1 + g2);
+            t[2][c] = 0.5f * (g0 - g1 + g2);
+            t[3][c] = g2;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), u3 = t[xi][2];
+            const float uu[4] = {u0, u1, u2, u3};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                dst[pass ? wino_frag_index(xi * 4 + nu, co, ci, Cout, Cin) : wino_frag_index(xi * 4 + nu, ci, co, Cin, Cout)] = uu[nu];
+        }
+    }
+}
+
+extern "C" size_t sed_conv3x3_wino_packed_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin + WN_ZTAIL; }
+extern "C" int sed_conv3x3_wino_pack_weights(const float* w, float* uf, float* ud, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(w && (uf || ud) && Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0, "conv3x3_wino_pack_weights: bad arguments (channel counts: multiples of 64)");
+    conv_pack_wino_k<<<cdiv(Cout * Cin, 256), 256, 0, as_stream(stream)>>>(w, uf, ud, Cout, Cin);
+    SED_LAUNCH_CHECK("conv_pack_wino");
+    return 0;
+}
+
+// ───────────────────────── geometry ─────────────────────────
+static bool wino_geo(int B, int Cin, int F, int T, int Cout, WinoGeo* g) {
+    if (B <= 0 || Cin != WN_CIN || Cout <= 0 || Cout % 64 != 0 || F < 2 || T < 2 || (F & 1) || (T & 1)) return false;
+    if ((size_t)B * T * F * Cin >= ((size_t)1 << 32) || (size_t)T * F * Cout >= ((size_t)1 << 30)) return false;
+    g->Fw = F / 2; g->Tw = T / 2; g->ntile = g->Fw * g->Tw; g->nblk = cdiv(g->ntile, 64);
+    int TR = 0;
+    for (int blk = 0; blk < g->nblk; ++blk) {
+        const int q1 = blk * 64 + 63 < g->ntile ? blk * 64 + 63 : g->ntile - 1;
+        const int n = q1 / g->Fw - (blk * 64) / g->Fw + 1;
+        if (n > TR) TR = n;
+    }
+    g->TR = TR; g->F2 = F + 2; g->H2 = g->F2 / 2; g->HR = (2 * TR + 2) * g->F2; g->nb8 = cdiv(g->HR, 8);
+    g->NH = cdiv(g->nb8, 4);
+    if (g->NH > WN_NHMAX) return false;
+    g->NH = WN_NHMAX;
+    g->ncoh = Cout / 64;
+    g->invFw = 1.0f / (float)g->Fw; g->invF2 = 1.0f / (float)g->F2;
+    // two patch buffers; the epilogue's exchange of the four waves' partial output transforms (4 x 2 x 2 x 2 tiles of 4 KB) + the
+    // statistics exchange reuse them; the row table behind
+    size_t fl = (size_t)2 * g->NH * 1024;
+    if (fl < 32768 + 512) fl = 32768 + 512;
+    g->lds = (fl + 64) * sizeof(float);
+    return g->lds <= 160 * 1024;
+}
+
+int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
+    WinoGeo g;
+    return wino_geo(B, Cin, F, T, Cout, &g) ? B * g.nblk : 0;
+}
+
+// ───────────────────────── the kernel ─────────────────────────
+template <int NH, bool BNR>
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
+    const float* __restrict__ x, const float* __restrict__ uq, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, WinoGeo geo, ConvBnRed br) {
+    constexpr int CIN = WN_CIN, NCHUNK = CIN / 32, NSTEP = 4 * NCHUNK;
+    constexpr int HBUF = NH * 1024;                       // floats per patch buffer (NH KiB per wave)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // workgroup -> (sequence, tile block, channel half).  Workgroups are dealt round-robin to the 8 XCDs in launch order: the
+    // channel halves of a block and the blocks of a sequence are given to the same XCD (they share the input patch through its L2)
+    int blk, coh, b;
+    {
+        const int bx = blockIdx.x, by = blockIdx.y;
+        if ((gridDim.y & 7) == 0) {
+            const int id = by * (int)gridDim.x + bx, xcd = id & 7, j = id >> 3;
+            coh = j % geo.ncoh;
+            const int jj = j / geo.ncoh;
+            b = xcd + 8 * (jj / geo.nblk);
+            blk = jj % geo.nblk;
+        } else {
+            coh = bx % geo.ncoh; blk = bx / geo.ncoh; b = by;
+        }
+    }
+    const int Fw = geo.Fw, F2 = geo.F2, H2 = geo.H2, ntile = geo.ntile;
+    const int q0 = blk * 64, ty0 = q0 / Fw;
+    const int co0 = coh * 64;
+
+    // this wave's row combination of B^T d: rows (ra, rb), d[ra] + sg d[rb]
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = wave == 1 ? 1.f : -1.f;
+
+    // LDS float offset of (patch position P, quad h) for the 2 m-tiles x 2 rows x 4 columns this lane reads every step
+    int aoff[2][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int q = q0 + mt * 32 + r;
+        q = q < ntile ? q : ntile - 1;
+        const int ty = sed_fdiv(q, geo.invFw), tf = q - ty * Fw;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int P = (2 * (ty - ty0) + (s ? rb : ra)) * F2 + tf + (c & 1) * H2 + (c >> 1);
+                aoff[mt][s][c] = (P >> 3) * 256 + h * 32 + (P & 7) * 4;
+            }
+    }
+
+    // patch staging (LDS-DMA): item = KiB block k = 4 u + wave, lane = 8 quad + position-in-block.  Every lane of every block issues
+    // (no branch: the loads interleave with the MFMAs); a lane whose position is zero padding, or lies past the patch, reads the
+    // zero tail behind the packed weights instead.
+    const float* hp[NH];
+    {
+        const int Q = lane >> 3, pp = lane & 7;
+        const float* zrow = uq + (size_t)16 * CIN * Cout;
+#pragma unroll
+        for (int u = 0; u < NH; ++u) {
+            const int P = (u * 4 + wave) * 8 + pp;
+            const int tt = sed_fdiv(P, geo.invF2), cx = P - tt * F2;
+            const int ff = cx < H2 ? 2 * cx : 2 * (cx - H2) + 1;
+            const int t = 2 * ty0 - 1 + tt, f = ff - 1;
+            const bool in = P < geo.HR && t >= 0 && t < T && f >= 0 && f < F;
+            hp[u] = in ? x + ((((size_t)b * T + t) * F + f) * CIN + Q * 4) : zrow + Q * 4;
+        }
+    }
+    auto issue = [&](int cc, float* buf) {
+#pragma unroll
+        for (int u = 0; u < NH; ++u)
+            __builtin_amdgcn_global_load_lds((sed_gptr_t)(hp[u] + cc * 32), (sed_lptr_t)(buf + (u * 4 + wave) * 256), 16, 0, 0);
+    };
+
+    // the epilogue's table: byte offset of output position (2 ty, 2 tf), channel 0, inside sequence b; ~0: no such tile
+    unsigned* rowtab = (unsigned*)(smem + (2 * HBUF > 32768 + 512 ? 2 * HBUF : 32768 + 512));
+    if (tid < 64) {
+        const int q = q0 + tid;
+        const int ty = sed_fdiv(q < ntile ? q : 0, geo.invFw), tf = q - ty * Fw;
+        rowtab[tid] = q < ntile ? (unsigned)(((2 * ty) * F + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
+    }
+
+    f32x16 acc[4][2][2];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[nu][mt][nt][j] = 0.f;
+
+    const f32x4* wl = (const f32x4*)uq + (size_t)(coh * 16 + wave * 4) * (NCHUNK * 4 * 2 * 64);      // wave-uniform
+    f32x4 bq[4][2];
+    auto load_b = [&](int nu, int st) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bq[nu][nt] = wl[((nu * NSTEP + st) * 2 + nt) * 64 + lane];
+    };
+    f32x4 va[2][2][4];
+    auto read_a = [&](const float* buf, int g, f32x4 (&v)[2][4]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 u[4], dA[4], dB[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                dA[c] = *(const f32x4*)(buf + aoff[mt][0][c] + g * 64);
+                dB[c] = *(const f32x4*)(buf + aoff[mt][1][c] + g * 64);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[c] = dA[c] + sg * dB[c];
+            v[mt][0] = u[0] - u[2];
+            v[mt][1] = u[1] + u[2];
+            v[mt][2] = u[2] - u[1];
+            v[mt][3] = u[1] - u[3];
+        }
+    };
+
+    issue(0, smem);
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) load_b(nu, 0);
+    __syncthreads();                                   // drains the DMA (vmcnt)
+    read_a(smem, 0, va[0]);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+        const int cc = st >> 2, g = st & 3, par = st & 1;
+        const bool more = cc + 1 < NCHUNK;
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 0 && more) issue(cc + 1, smem + ((cc + 1) & 1) * HBUF);      // that buffer was last read before the barrier of step (cc-1, 2)
+        if (st + 1 < NSTEP) read_a(smem + (((st + 1) >> 2) & 1) * HBUF, (st + 1) & 3, va[par ^ 1]);
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[par][mt][nu][j], bq[nu][nt][j], acc[nu][mt][nt], 0, 0, 0);
+            if (st + 1 < NSTEP) load_b(nu, st + 1);
+        }
+        // one MFMA, then up to two of the other instructions (transform arithmetic, LDS reads, fragment loads, DMA): one wave per
+        // SIMD issues in order, what sits between two MFMAs must fit the 64-cycle shadow of the one in front
+        // the 16 operand reads of the next step ride in the first 16 gaps, their arithmetic after them
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            if ((i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 2 && more) __syncthreads();           // the next slice's patch is complete (DMA drained) and visible
+    }
+    __syncthreads();                                   // every wave has read its last operands: the patch buffers are free
+
+    // ── output transform ──
+    // along nu in registers: Z_j = (M0 + M1 + M2, M1 - M2 - M3); each wave parks its Z[xi][j][mt][nt] as a transposed 32 x 32 tile
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x16 z0 = acc[0][mt][nt] + acc[1][mt][nt] + acc[2][mt][nt];
+            const f32x16 z1 = acc[1][mt][nt] - acc[2][mt][nt] - acc[3][mt][nt];
+            float* zb0 = smem + ((((wave * 2 + 0) * 2 + mt) * 2 + nt) << 10);
+            float* zb1 = smem + ((((wave * 2 + 1) * 2 + mt) * 2 + nt) << 10);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                zb0[row * 32 + r] = z0[j];
+                zb1[row * 32 + r] = z1[j];
+            }
+        }
+    __syncthreads();
+    // across xi: wave w finishes m-tile w >> 1, channel tile w & 1; lane = (row group rq, channels c4 .. c4+3)
+    const int mt = wave >> 1, nt = wave & 1;
+    const int rq = lane >> 3, c4 = (lane & 7) * 4;
+    const int cb = co0 + nt * 32 + c4;
+    f32x4 bv = {0, 0, 0, 0};
+    if (bias) bv = *(const f32x4*)(bias + cb);
+    char* const yb = (char*)(y + (size_t)b * T * F * Cout + cb);
+    const char* const qb = BNR ? (const char*)(br.pooled + (size_t)b * T * F * Cout + cb) : nullptr;
+    f32x4 q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    if (BNR) {
+        const f32x4 q_beta = *(const f32x4*)(br.beta + cb);
+        const f32x4 gm = *(const f32x4*)(br.gamma + cb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool zero = gm[e] == 0.f || (br.ybelow != nullptr && fabsf(gm[e]) * 64.f < fabsf(q_beta[e]));
+            const float rg = zero ? 0.f : 1.0f / gm[e];
+            q_kr[e] = br.keep * rg;
+            q_nb[e] = -q_beta[e] * rg;
+        }
+    }
+    const unsigned rstride = (unsigned)(F * Cout) * 4u, cstride = (unsigned)Cout * 4u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = rq + 8 * k;
+        const unsigned ro = rowtab[mt * 32 + m];
+        if (ro == 0xFFFFFFFFu) continue;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            f32x4 z[4];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) z[xi] = *(const f32x4*)(smem + ((((xi * 2 + jj) * 2 + mt) * 2 + nt) << 10) + m * 32 + c4);
+            const f32x4 o[2] = {z[0] + z[1] + z[2] + bv, z[1] - z[2] - z[3] + bv};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = ro + i * rstride + jj * cstride;
+                const f32x4 v = o[i];
+                *(f32x4*)(yb + off) = v;
+                if (BNR) {
+                    const f32x4 pq = *(const f32x4*)(qb + off);
+                    f32x4 g0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g0[e] = pq[e] > 0.f ? v[e] : 0.f;
+                    a1 += g0;
+                    a2 += g0 * (pq * q_kr + q_nb);
+                } else {
+                    a1 += v;
+                    a2 += v * v;
+                }
+            }
+        }
+    }
+    if (stat) {
+        // a1 / a2: forward (sum y, sum y^2), data gradient (sum g, sum g*xhat) of this lane's four channels over its rows
+        float* red = smem + 32768;                    // [4 waves][2][32] behind the exchange tiles
+        if (BNR) { a1 *= br.inv_keep; a2 *= br.inv_keep; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) { a1[e] += __shfl_xor(a1[e], o, 64); a2[e] += __shfl_xor(a2[e], o, 64); }
+        }
+        if (lane < 8) {
+            *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
+            *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63, cn = c >> 5, cr = c & 31;
+            const float a = red[((0 * 2 + cn) * 2 + which) * 32 + cr] + red[((1 * 2 + cn) * 2 + which) * 32 + cr];
+            stat[((size_t)b * geo.nblk + blk) * 2 * Cout + which * Cout + co0 + c] = a;
+        }
+    }
+}
+
+template <typename K>
+static int wino_set_lds(K kernel, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { sed_set_error("hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int sed_internal_wino_launch(const float* x, const float* uq, const float* bias, float* y, float* stat, const ConvBnRed* br,
+                             int rgc, int B, int Cin, int F, int T, int Cout, hipStream_t s) {
+    WinoGeo g;
+    SED_REQUIRE(wino_geo(B, Cin, F, T, Cout, &g), "conv3x3_wino: shape B=%d Cin=%d F=%d T=%d Cout=%d is not supported (sed_conv3x3_wino_rows)", B, Cin, F, T, Cout);
+    SED_REQUIRE(rgc == 0, "conv3x3_wino: the first block's tap sums are not formed by this kernel");
+    const dim3 grid(g.nblk * g.ncoh, B);
+    const ConvBnRed none{};
+#define WN_LAUNCH(NHv, BNRv)                                                                                              \
+    do {                                                                                                                   \
+        SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv>), g.lds));                                                         \
+        conv3x3_wino_k<NHv, BNRv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);       \
+    } while (0)
+    if (br) WN_LAUNCH(WN_NHMAX, true); else WN_LAUNCH(WN_NHMAX, false);
+#undef WN_LAUNCH
+    SED_LAUNCH_CHECK("conv3x3_wino");
+    return 0;
+}
+
+extern "C" int sed_conv3x3_wino_rows(int B, int Cin, int F, int T, int Cout) { return sed_internal_wino_rows(B, Cin, F, T, Cout); }
+
+extern "C" int sed_conv3x3_wino_fwd(const float* x, const float* uq, const float* bias, float* y, float* stat,
+                                    int B, int Cin, int F, int T, int Cout, void* stream) {
+    SED_REQUIRE(x && uq && y, "conv3x3_wino_fwd: null pointer");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_FWD, s, 2.0 * 9.0 * Cin * Cout * (double)B * T * F);
+    return sed_internal_wino_launch(x, uq, bias, y, stat, nullptr, 0, B, Cin, F, T, Cout, s);
+}
+
+extern "C" int sed_conv3x3_wino_dgrad_bnred(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,
+                                            const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
+                                            const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
+                                            int B, int C, int F, int T, int Cin, void* stream) {
+    SED_REQUIRE(dy && ud && dx && partials && pooled && gamma && beta && mean && rstd, "conv3x3_wino_dgrad_bnred: null pointer");
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f && pool_f >= 1 && pool_t >= 1, "conv3x3_wino_dgrad_bnred: bad drop_p / pool");
+    SED_REQUIRE(Ty / pool_t == T && Fy / pool_f == F, "conv3x3_wino_dgrad_bnred: conv output %dx%d does not pool (%d,%d) to %dx%d", Ty, Fy, pool_f, pool_t, T, F);
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_DGRAD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
+    const ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty,
+                       nullptr, nullptr, nullptr, 0.f};
+    return sed_internal_wino_launch(dy, ud, nullptr, dx, partials, &br, 0, B, C, F, T, Cin, s);
+}

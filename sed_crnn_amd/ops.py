@@ -41,6 +41,28 @@ def conv3x3_fwd(x, wp, bias, x_is_nchw, want_stats=True, mode=0):
     return y, stat
 
 
+def conv3x3_wino_pack(w):
+    """w [Cout,Cin,3,3] -> (uf, ud): the Winograd F(2x2,3x3) transformed weights of the forward and of the data gradient"""
+    Cout, Cin = w.shape[:2]
+    n = lib().sed_conv3x3_wino_packed_floats(Cout, Cin)
+    uf, ud = torch.empty(n, device=w.device), torch.empty(n, device=w.device)
+    check(lib().sed_conv3x3_wino_pack_weights(ptr(_f32c(w)), ptr(uf), ptr(ud), Cout, Cin, stream_ptr()), "conv3x3_wino_pack")
+    return uf, ud
+
+
+def conv3x3_wino_fwd(x, up, bias, Cout, want_stats=True):
+    """x [B,T,F,128] channels-last, up from conv3x3_wino_pack -> y [B,T,F,Cout] (+ statistic partial rows)"""
+    B, T, F, Cin = x.shape
+    rows = lib().sed_conv3x3_wino_rows(B, Cin, F, T, Cout)
+    if rows <= 0:
+        raise ValueError("conv3x3_wino_fwd: shape not supported")
+    y = torch.empty(B, T, F, Cout, device=x.device)
+    stat = torch.zeros(rows, 2, Cout, device=x.device) if want_stats else None
+    check(lib().sed_conv3x3_wino_fwd(ptr(_f32c(x)), ptr(_f32c(up)), ptr(bias), ptr(y), ptr(stat), B, Cin, F, T, Cout, stream_ptr()),
+          "conv3x3_wino_fwd")
+    return y, stat
+
+
 def conv3x3_bn_relu_pool_eval(x, w, bias, gamma, beta, running_mean, running_var, eps=1e-5):
     """inference: x [B,T,F,Cin] channels-last -> relu(max_pool((1,2))(bn_eval(conv3x3(x)))) [B,T//2,F,Cout] in one launch
     (BatchNorm folded into the packed weights; sed_conv3x3_pack_weights_bn_folded + sed_conv3x3_bn_relu_pool_eval)"""
@@ -138,21 +160,23 @@ def bn_bwd_sums_from_pooled(pooled, dout, gamma, beta, y, mean, rstd, pool_f, po
     return sum_g, sum_gx
 
 
-def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0, scale=None, shift=None):
+def conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, y_below, mean, rstd, pool_f, pool_t, drop_p=0.0, scale=None, shift=None, wino=False):
     """data gradient of a conv block + the BatchNorm-backward sums of the block below in its epilogue
-    -> (dx [B,T,F,Cin], sum_g [Cin], sum_gx [Cin]); dy [B,T,F,C], wd = the dgrad packing [9,Cin,C]"""
+    -> (dx [B,T,F,Cin], sum_g [Cin], sum_gx [Cin]); dy [B,T,F,C], wd = the dgrad packing [9,Cin,C] (wino: the `ud` of
+    conv3x3_wino_pack and the Winograd kernel)"""
     B, T, F, Cc = dy.shape
     Cin = pooled.shape[-1]
-    rows = lib().sed_conv3x3_dgrad_bnred_rows(B, Cc, F, T, Cin)
+    rows = lib().sed_conv3x3_wino_rows(B, Cc, F, T, Cin) if wino else lib().sed_conv3x3_dgrad_bnred_rows(B, Cc, F, T, Cin)
     assert rows > 0, "shape does not take the fused MFMA path"
     dx = torch.empty(B, T, F, Cin, device=dy.device)
     part = torch.empty(rows, 2, Cin, device=dy.device)
     if scale is None:
         scale = gamma * rstd
         shift = beta - mean * scale
-    check(lib().sed_conv3x3_dgrad_bnred(ptr(_f32c(dy)), ptr(_f32c(wd)), ptr(dx), ptr(part), ptr(_f32c(pooled)), ptr(gamma), ptr(beta),
-                                        ptr(_f32c(y_below)), ptr(mean), ptr(rstd), drop_p, pool_f, pool_t, y_below.shape[2],
-                                        y_below.shape[1], B, Cc, F, T, Cin, stream_ptr()), "conv3x3_dgrad_bnred")
+    entry = lib().sed_conv3x3_wino_dgrad_bnred if wino else lib().sed_conv3x3_dgrad_bnred
+    check(entry(ptr(_f32c(dy)), ptr(_f32c(wd)), ptr(dx), ptr(part), ptr(_f32c(pooled)), ptr(gamma), ptr(beta),
+                ptr(_f32c(y_below)), ptr(mean), ptr(rstd), drop_p, pool_f, pool_t, y_below.shape[2],
+                y_below.shape[1], B, Cc, F, T, Cin, stream_ptr()), "conv3x3_dgrad_bnred")
     sum_g, sum_gx = torch.empty(Cin, device=dy.device), torch.empty(Cin, device=dy.device)
     # (a stored conv output below: the small-|gamma| channels are finished from it by the finalising kernel)
     check(lib().sed_bn_bwd_finalize_small_gamma(ptr(part), rows, Cin, ptr(sum_g), ptr(sum_gx), None, None, ptr(dx), ptr(pooled),

@@ -279,6 +279,76 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
         assert float(sum_gx[c].abs()) > 0.0
 
 
+@pytest.mark.parametrize("B,Fm,T,Cout", [(2, 40, 16, 128), (1, 40, 128, 128), (3, 40, 6, 128), (2, 20, 10, 64), (1, 10, 64, 128),
+                                          (2, 8, 2, 256), (1, 2, 2, 128), (9, 32, 12, 128), (8, 40, 64, 128)])
+def test_conv3x3_winograd_forward_and_data_gradient(ops, B, Fm, T, Cout):
+    """The Winograd F(2x2,3x3) form of the 128-channel convolutions (wino.hip) against torch in float64, next to the direct
+    exact-fp32 kernel on the same inputs: forward with bias and the statistic partial rows, and the data gradient (same kernel,
+    flipped / transposed transformed weights).  Mel widths whose tile rows do not divide the 64-tile blocks (40, 20, 10), blocks
+    that end in the middle of a sequence's last tile row, a single tile, batch sizes with and without the XCD-aware order.  The
+    transforms only add and halve, so the error stays within a small multiple of the direct kernel's (asserted: 4x + an ulp term)."""
+    torch.manual_seed(B * 7 + Fm + T)
+    Cin = 128
+    x = torch.randn(B, T, Fm, Cin)
+    w = torch.randn(Cout, Cin, 3, 3) / (3.0 * Cin ** 0.5)
+    bias = torch.randn(Cout)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 2, 1).double(), w.double(), bias.double(), padding=1).permute(0, 3, 2, 1).contiguous()
+    uf, _ = ops.conv3x3_wino_pack(w.cuda())
+    y, stat = ops.conv3x3_wino_fwd(x.cuda(), uf, bias.cuda(), Cout)
+    wf0, _ = ops.conv3x3_pack(w.cuda())
+    y0, _ = ops.conv3x3_fwd(x.cuda(), wf0, bias.cuda(), False)
+    scale = float(ref.abs().mean())
+    err, err0 = (y.cpu().double() - ref).abs(), (y0.cpu().double() - ref).abs()
+    print(f"winograd fwd B={B} F={Fm} T={T}: max err {float(err.max()):.2e} mean {float(err.mean()):.2e} | direct max {float(err0.max()):.2e} "
+          f"mean {float(err0.mean()):.2e} | scale {scale:.2e}")
+    assert float(err.max()) < 4.0 * float(err0.max()) + 2e-6 * scale and float(err.mean()) < 4.0 * float(err0.mean()) + 2e-7 * scale
+    assert float(err.max()) < 2e-5 * scale * 10                      # an absolute bound too: ~1e-5 of the output magnitude
+    s = stat.sum(0).cpu().double()
+    torch.testing.assert_close(s[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=2e-5 * scale * B * T * Fm)
+    torch.testing.assert_close(s[1], (ref * ref).sum((0, 1, 2)), rtol=1e-4, atol=1e-4)
+    assert torch.equal(y, ops.conv3x3_wino_fwd(x.cuda(), uf, bias.cuda(), Cout)[0])          # fixed order: run to run identical
+    if Cout == Cin:
+        dy = torch.randn(B, T, Fm, Cout)
+        dref = torch.nn.grad.conv2d_input((B, Cin, Fm, T), w.double(), dy.permute(0, 3, 2, 1).contiguous().double(), padding=1).permute(0, 3, 2, 1)
+        _, ud = ops.conv3x3_wino_pack(w.cuda())
+        dx, _ = ops.conv3x3_wino_fwd(dy.cuda(), ud, None, Cin, want_stats=False)
+        _, wd0 = ops.conv3x3_pack(w.cuda())
+        dx0, _ = ops.conv3x3_fwd(dy.cuda(), wd0, None, False, want_stats=False)
+        derr, derr0 = (dx.cpu().double() - dref).abs(), (dx0.cpu().double() - dref).abs()
+        assert float(derr.max()) < 4.0 * float(derr0.max()) + 2e-6 * float(dref.abs().mean()), (float(derr.max()), float(derr0.max()))
+
+
+@pytest.mark.parametrize("B,Ty,Fy,pf,pt,p", [(3, 16, 40, 1, 2, 0.5), (2, 12, 40, 1, 2, 0.0), (2, 8, 64, 1, 2, 0.5), (1, 8, 40, 2, 1, 0.25)])
+def test_winograd_dgrad_with_fused_bn_backward_reduction(ops, B, Ty, Fy, pf, pt, p):
+    """sed_conv3x3_wino_dgrad_bnred against sed_conv3x3_dgrad_bnred (the direct kernel with the same epilogue): dx to the
+    Winograd rounding, (sum g, sum g*xhat) of the block below to the tolerance the direct form is held to against the two-pass
+    reference — the gate `pooled > 0` comes from the forward's tensor, so the selection is identical."""
+    C = 128
+    gen = torch.Generator().manual_seed(B * 100 + Ty + Fy)
+    yb = torch.randn(B, Ty, Fy, C, generator=gen).cuda()
+    gamma = (torch.rand(C, generator=gen) + 0.5)
+    beta = torch.randn(C, generator=gen) * 0.3
+    gamma[3], beta[3] = 0.0, 0.5
+    gamma[100] = -0.7
+    gamma[8], beta[8] = 1e-3, 0.5
+    gamma, beta = gamma.cuda(), beta.cuda()
+    flat = yb.reshape(-1, C)
+    part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).reshape(1, 2, C).contiguous()
+    mean, rstd, scale, shift = ops.bn_finalize_train(part, B * Ty * Fy, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda())
+    pooled = ops.bn_relu_pool_drop_fwd(yb, scale, shift, pf, pt, drop_p=p, seed=99)
+    T, Fm = Ty // pt, Fy // pf
+    dy = (torch.randn(B, T, Fm, C, generator=gen) * 0.1).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=gen) / np.sqrt(9 * C)).cuda()
+    _, wd = ops.conv3x3_pack(w)
+    _, ud = ops.conv3x3_wino_pack(w)
+    dx0, sg0, sgx0 = ops.conv3x3_dgrad_bnred(dy, wd, pooled, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p, scale=scale, shift=shift)
+    dx, sg, sgx = ops.conv3x3_dgrad_bnred(dy, ud, pooled, gamma, beta, yb, mean, rstd, pf, pt, drop_p=p, scale=scale, shift=shift, wino=True)
+    close(dx, dx0, atol=2e-6 * float(dx0.abs().mean()) * 10, rtol=1e-5)
+    mag = float((dx0.abs() / (1.0 - p)).sum(dim=(0, 1, 2)).max())
+    close(sg, sg0, atol=2e-6 * mag, rtol=1e-4)
+    close(sgx, sgx0, atol=6e-6 * mag, rtol=1e-4)
+
+
 @pytest.mark.parametrize("B,Ty,Fy,C,pf,pt,p", [(3, 16, 40, 128, 1, 2, 0.5), (2, 12, 40, 128, 1, 2, 0.0), (2, 9, 40, 128, 1, 2, 0.5),
                                                 (1, 8, 128, 128, 1, 2, 0.5), (2, 6, 48, 64, 3, 1, 0.25), (5, 4, 16, 32, 2, 2, 0.3)])
 def test_bn_backward_sums_of_the_gru_feeding_block_from_its_pooled_output(ops, B, Ty, Fy, C, pf, pt, p):

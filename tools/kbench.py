@@ -39,6 +39,9 @@ def main():
             ms = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, False), a.iters)
             fl = 2 * 9 * 128 * 128 * B * T * 40
             print(f"conv3x3_mfma_fwd  B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+            uf, _ = ops.conv3x3_wino_pack(w)
+            ms = timeit(lambda: ops.conv3x3_wino_fwd(x, uf, bias, 128), a.iters)
+            print(f"conv3x3 winograd F(2x2,3x3)  B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} algorithmic TFLOP/s ({fl/2.25/ms/1e9:.1f} executed)")
             wfb, _ = ops.conv3x3_pack(w, mode=1)
             ms = timeit(lambda: ops.conv3x3_fwd(x, wfb, bias, False, mode=1), a.iters)
             print(f"conv3x3 bf16x3 (experiment)  B{B} T{T}: {ms:.3f} ms  {fl/ms/1e9:.1f} fp32-equivalent TFLOP/s")
