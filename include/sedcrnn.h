@@ -449,6 +449,7 @@ typedef struct sed_net_cfg {
  * order, which must give the same gradients at the same speed.  SED_NET_NO_GATE (A/B measurements): no gate. */
 #define SED_NET_AUX_FIRST 0x1
 #define SED_NET_NO_GATE 0x2
+#define SED_NET_DIRECT_CONV 0x4     /* the 128-channel blocks on the direct 3x3 kernels instead of the Winograd form (A/B measurements, tests) */
 
 typedef struct sed_net_params {      /* pointers in the reference's own layouts */
     float* conv_w[SED_MAX_CONV];      /* [C][Cin][3][3] */

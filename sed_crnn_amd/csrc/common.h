@@ -47,8 +47,9 @@ struct SedProfScope {
 
 // internal (conv.hip): the fp32 weight packing of up to SED_MAX_CONV layers in ONE launch (the forward packs every conv layer
 // of a step up front instead of once per layer on the critical chain); same layouts as sed_conv3x3_pack_weights
+// wino_f / wino_d (may be NULL): per layer, wf / wd receives the Winograd-transformed packing of wino.hip instead
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
-                                 void* stream);
+                                 const int* wino_f, const int* wino_d, void* stream);
 
 // internal (conv.hip): the inference form of the packing launch — every layer's fragments, the BatchNorm coefficients on running
 // statistics, BatchNorm folded into weights + bias where fold[l], and (perm_src) the GRU input weights re-ordered to

@@ -145,6 +145,7 @@ struct ConvPackMulti {
     const float* gamma[SED_MAX_CONV]; const float* beta[SED_MAX_CONV]; const float* rm[SED_MAX_CONV]; const float* rv[SED_MAX_CONV];
     const float* bias[SED_MAX_CONV]; float* scale_out[SED_MAX_CONV]; float* shift_out[SED_MAX_CONV]; float* bias_out[SED_MAX_CONV];
     int fold[SED_MAX_CONV]; float eps;
+    int wino_f[SED_MAX_CONV], wino_d[SED_MAX_CONV];      // wf / wd of this layer is the Winograd-transformed packing (wino.hip) instead
     // one more slice of the grid (blockIdx.y == n): a row-major [rows][C*Fp] matrix whose columns are re-ordered from the
     // reference's GRU feature order c*Fp + f (sed.py:108-110) to the channels-last order f*C + c of a pooled conv output
     const float* perm_src[2]; float* perm_dst; int perm_rows, perm_C, perm_Fp;      // two sources of perm_rows rows each -> [2 perm_rows][K]
@@ -170,6 +171,7 @@ __global__ void conv_pack_w_multi_k(ConvPackMulti a, int n) {
         return;
     }
     const int Cout = a.Cout[l], Cin = a.Cin[l];
+    if (a.wino_f[l] | a.wino_d[l]) wino_pack_one(a.w[l], a.wino_f[l] ? a.wf[l] : nullptr, a.wino_d[l] ? a.wd[l] : nullptr, Cout, Cin, i);
     if (a.gamma[l] && i < Cout) {
         const float sc = a.gamma[l][i] / sqrtf(a.rv[l][i] + a.eps), sh = a.beta[l][i] - a.rm[l][i] * sc;      // = bn_finalize_eval_k
         if (a.scale_out[l]) { a.scale_out[l][i] = sc; a.shift_out[l][i] = sh; }
@@ -180,8 +182,8 @@ __global__ void conv_pack_w_multi_k(ConvPackMulti a, int n) {
     float v = a.w[l][i];
     if (a.fold[l]) v *= a.gamma[l][co] / sqrtf(a.rv[l][co] + a.eps);
     const bool frag = (Cin % 32 == 0) && (Cout % 32 == 0);
-    if (a.wf[l]) a.wf[l][frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
-    if (a.wd[l]) a.wd[l][frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
+    if (a.wf[l] && !a.wino_f[l]) a.wf[l][frag ? conv_frag_index(tap, co, ci, Cout, Cin) : ((size_t)tap * Cout + co) * Cin + ci] = v;
+    if (a.wd[l] && !a.wino_d[l]) a.wd[l][frag ? conv_frag_index(8 - tap, ci, co, Cin, Cout) : ((size_t)(8 - tap) * Cin + ci) * Cout + co] = v;
 }
 static int set_lds_early(size_t bytes) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_pack_w_multi_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -203,12 +205,15 @@ static int pack_multi_launch(const ConvPackMulti& a, int n, void* stream) {
     return 0;
 }
 int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf, float* const* wd, const int* Cout, const int* Cin,
-                                 void* stream) {
+                                 const int* wino_f, const int* wino_d, void* stream) {
     SED_REQUIRE(n > 0 && n <= SED_MAX_CONV && w && wf && wd && Cout && Cin, "conv_pack_multi: bad arguments");
     ConvPackMulti a{};
     for (int l = 0; l < n; ++l) {
         SED_REQUIRE(w[l] && Cout[l] > 0 && Cin[l] > 0, "conv_pack_multi: bad layer %d", l);
         a.w[l] = w[l]; a.wf[l] = wf[l]; a.wd[l] = wd[l]; a.Cout[l] = Cout[l]; a.Cin[l] = Cin[l];
+        a.wino_f[l] = (wino_f && wino_f[l] && wf[l]) ? 1 : 0;
+        a.wino_d[l] = (wino_d && wino_d[l] && wd[l]) ? 1 : 0;
+        SED_REQUIRE(!(a.wino_f[l] | a.wino_d[l]) || (Cout[l] % 64 == 0 && Cin[l] % 64 == 0), "conv_pack_multi: layer %d cannot take the Winograd packing", l);
     }
     return pack_multi_launch(a, n, stream);
 }

@@ -13,6 +13,7 @@ struct ConvL { int Cin, C, T, F, Tp, Fp, pf, pt, rows, bn_rows, nchw, fused; flo
                int red_rows;      // > 0: this block's BatchNorm-backward sums come out of the data gradient of the block above (that many partial rows)
                int rg_rows;       // > 0 (block 0 only): so do its weight-gradient sums (sed_conv3x3_dgrad_bnred_rg), into c1_ws
                int rgrad;         // recomputed first block: its weight gradient comes from the pooled output, arg-max bits and input moments
+               int wino, wino_d;  // forward / data gradient of this block run as Winograd F(2x2,3x3) (wino.hip)
                int ev; };         // inference plan only: BatchNorm folded into the packed weights, ReLU + (1,2) pool in the conv epilogue
                                   // (sed_conv3x3_bn_relu_pool_eval): the block's un-pooled output is never written
 struct GruL { int in, H; };
@@ -52,7 +53,7 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     SED_REQUIRE(c->n_gru >= 1 && c->n_gru <= SED_MAX_GRU, "net: n_gru=%d out of range", c->n_gru);
     SED_REQUIRE(c->n_dense >= 1 && c->n_dense <= SED_MAX_DENSE, "net: n_dense=%d out of range", c->n_dense);
     SED_REQUIRE(c->conv_mode == 0 || c->conv_mode == 1, "net: conv_mode=%d (0 = exact fp32, 1 = bf16x3 experiment)", c->conv_mode);
-    SED_REQUIRE((c->flags & ~(SED_NET_AUX_FIRST | SED_NET_NO_GATE)) == 0, "net: unknown flags 0x%x", c->flags);
+    SED_REQUIRE((c->flags & ~(SED_NET_AUX_FIRST | SED_NET_NO_GATE | SED_NET_DIRECT_CONV)) == 0, "net: unknown flags 0x%x", c->flags);
     memset(L, 0, sizeof(*L));
     L->n_conv = c->n_conv; L->n_gru = c->n_gru; L->n_dense = c->n_dense;
     Carver cv;
@@ -77,11 +78,15 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
             sed_conv1_rgrad_supported(q.Cin, q.F, q.T, q.C, q.pf, q.pt) &&
             sed_conv3x3_dgrad_bnred_rows(c->B, c->C[1], q.F / q.pf, q.T / q.pt, q.C) > 0)
             q.fused = 1;
+        // 128 input channels, exact fp32: the Winograd form (2.25x fewer MFMAs, same epilogues) unless the caller asks for the direct kernels
+        const bool wino_ok = l > 0 && c->conv_mode == 0 && !(c->flags & SED_NET_DIRECT_CONV);
+        q.wino = (wino_ok && sed_conv3x3_wino_rows(c->B, q.Cin, q.F, q.T, q.C) > 0) ? 1 : 0;
+        q.wino_d = (wino_ok && training && sed_conv3x3_wino_rows(c->B, q.C, q.F, q.T, q.Cin) > 0) ? 1 : 0;
         if (q.fused) {
             q.rows = 1;                                        // statistics from the input moments: one partial row
             q.bn_rows = sed_conv1_fused_rows(c->B, q.T);
         } else {
-            q.rows = sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
+            q.rows = q.wino ? sed_conv3x3_wino_rows(c->B, q.Cin, q.F, q.T, q.C) : sed_conv3x3_stat_rows(c->B, q.Cin, q.F, q.T, q.C, q.nchw);
             SED_REQUIRE(q.rows > 0, "net: conv block %d (Cin=%d C=%d F=%d) is not supported by any conv kernel", l, q.Cin, q.C, q.F);
             q.bn_rows = sed_bn_bwd_rows(c->B, q.T, q.pt);
         }
@@ -89,9 +94,10 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         // epilogue; everything else (and every training plan) keeps the conv output + the BatchNorm/ReLU/pool pass
         q.ev = (!training && l > 0 && c->conv_mode == 0 && q.pf == 1 && q.pt == 2 &&
                 sed_conv3x3_bn_relu_pool_eval_supported(c->B, q.Cin, q.F, q.T, q.C)) ? 1 : 0;
+        if (q.ev) q.wino = 0;
         size_t nout = (q.fused || q.ev) ? 64 : (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
-        L->wp_f[l] = cv.take((size_t)9 * q.C * q.Cin);
-        L->wp_d[l] = cv.take((size_t)9 * q.C * q.Cin);
+        L->wp_f[l] = cv.take(q.wino ? sed_conv3x3_wino_packed_floats(q.C, q.Cin) : (size_t)9 * q.C * q.Cin);
+        L->wp_d[l] = cv.take(q.wino_d ? sed_conv3x3_wino_packed_floats(q.C, q.Cin) : (size_t)9 * q.C * q.Cin);
         L->conv_out[l] = cv.take(nout);
         L->stat[l] = cv.take((size_t)q.rows * 2 * q.C);
         L->mean[l] = cv.take(q.C); L->rstd[l] = cv.take(q.C); L->scale[l] = cv.take(q.C); L->shift[l] = cv.take(q.C);
@@ -127,12 +133,13 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
     // exact-fp32 MFMA blocks: the data gradient of block l forms the BatchNorm-backward sums of block l-1 in its epilogue
     for (int l = 1; l < c->n_conv; ++l) {
         const ConvL& q = L->cv[l];
-        const int rr = (c->conv_mode == 0) ? sed_conv3x3_dgrad_bnred_rows(c->B, q.C, q.F, q.T, q.Cin) : 0;
+        const int rr = (c->conv_mode != 0) ? 0 : q.wino_d ? sed_conv3x3_wino_rows(c->B, q.C, q.F, q.T, q.Cin)
+                                                           : sed_conv3x3_dgrad_bnred_rows(c->B, q.C, q.F, q.T, q.Cin);
         L->cv[l - 1].red_rows = rr;
         if (rr > max_bn_rows) max_bn_rows = rr;
         // ... and, for the recomputed first block with 1 or 2 input channels, its weight-gradient sums too (1 + 9 Cin floats per
         // channel and workgroup)
-        if (l == 1 && rr > 0 && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin <= 2) {
+        if (l == 1 && rr > 0 && !q.wino_d && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin <= 2) {
             const int gr = sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin, L->cv[0].Cin);
             L->cv[0].rg_rows = gr;
             const size_t need = (size_t)gr * q.Cin * (1 + 9 * L->cv[0].Cin);
@@ -286,12 +293,13 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
     const bool packed_up_front = !eval_plan && pb == 0 && c->conv_mode == 0 && L.n_conv > 1;
     if (packed_up_front) {
         const float* w[SED_MAX_CONV]; float* wf[SED_MAX_CONV]; float* wd[SED_MAX_CONV]; int co[SED_MAX_CONV], ci[SED_MAX_CONV];
+        int wnf[SED_MAX_CONV], wnd[SED_MAX_CONV];
         for (int l = 0; l < L.n_conv; ++l) {
             SED_REQUIRE(p->conv_w[l], "net_forward: missing parameters of conv block %d", l);
             w[l] = p->conv_w[l]; wf[l] = ws + L.wp_f[l]; wd[l] = (training && l > 0) ? ws + L.wp_d[l] : nullptr;
-            co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin;
+            co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin; wnf[l] = L.cv[l].wino; wnd[l] = L.cv[l].wino_d;
         }
-        SED_TRY(sed_internal_conv_pack_multi(L.n_conv, w, wf, wd, co, ci, stream));
+        SED_TRY(sed_internal_conv_pack_multi(L.n_conv, w, wf, wd, co, ci, wnf, wnd, stream));
     }
     for (int l = 0; l < L.n_conv && !eval_plan; ++l) {
         const ConvL& q = L.cv[l];
@@ -302,12 +310,20 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
                     "net_forward: missing parameters of conv block %d", l);
         if (do_a) {
-            if (!packed_up_front)
-                SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], ws + L.wp_f[l], (training && l > 0) ? ws + L.wp_d[l] : nullptr,
-                                                    q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
+            if (!packed_up_front) {
+                float* const wdp = (training && l > 0) ? ws + L.wp_d[l] : nullptr;
+                if (q.wino || (q.wino_d && wdp))
+                    SED_TRY(sed_conv3x3_wino_pack_weights(p->conv_w[l], q.wino ? ws + L.wp_f[l] : nullptr, q.wino_d ? wdp : nullptr, q.C, q.Cin, stream));
+                if (!q.wino || (wdp && !q.wino_d))
+                    SED_TRY(sed_conv3x3_pack_weights_ex(p->conv_w[l], q.wino ? nullptr : ws + L.wp_f[l], q.wino_d ? nullptr : wdp,
+                                                        q.C, q.Cin, (l > 0) ? c->conv_mode : 0, stream));
+            }
             if (q.fused) {
                 if (training) SED_TRY(sed_conv1_stats(in, ws + L.wp_f[l], p->conv_b[l], ws + L.stat[l], ws + L.c1_stat_ws, B, q.Cin, q.F, q.T, q.C,
                                                       q.rgrad ? (double*)(ws + L.c1_mom) : nullptr, stream));
+            } else if (q.wino) {
+                SED_TRY(sed_conv3x3_wino_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l], training ? ws + L.stat[l] : nullptr,
+                                             B, q.Cin, q.F, q.T, q.C, stream));
             } else {
                 SED_TRY(sed_conv3x3_fwd_ex(in, q.nchw, ws + L.wp_f[l], p->conv_b[l], ws + L.conv_out[l],
                                            training ? ws + L.stat[l] : nullptr, B, q.Cin, q.F, q.T, q.C, (l > 0) ? c->conv_mode : 0, stream));
@@ -537,6 +553,10 @@ static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p,
         return sed_conv3x3_dgrad_bnred_rg(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                           p->bn_g[l - 1], p->bn_b[l - 1], ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop,
                                           x, u.Cin, (const unsigned char*)(ws + L.c1_bits), ws + L.c1_ws, c->B, q.C, q.F, q.T, q.Cin, st);
+    if (q.wino_d)
+        return sed_conv3x3_wino_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
+                                            p->bn_g[l - 1], p->bn_b[l - 1], u.fused ? nullptr : ws + L.conv_out[l - 1],
+                                            ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop, u.pf, u.pt, u.F, u.T, c->B, q.C, q.F, q.T, q.Cin, st);
     if (u.red_rows > 0)
         return sed_conv3x3_dgrad_bnred(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                        p->bn_g[l - 1], p->bn_b[l - 1],

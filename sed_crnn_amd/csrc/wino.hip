@@ -45,51 +45,8 @@ struct WinoGeo {
 };
 
 // ───────────────────────── weight transform + packing ─────────────────────────
-// fragment order [co/64][component][ci/32][(ci%32)/8][(co%64)/32][lane = co%32 + 32 ((ci%8)/4)][ci%4]: everything a workgroup (one
-// channel half) streams is one contiguous 16 K 64 floats, and inside it every (component, step, channel tile) offset is a constant
-__host__ __device__ inline size_t wino_frag_index(int comp, int k, int n, int K, int N) {
-    const int cc = k >> 5, g = (k & 31) >> 3, h = (k & 7) >> 2, j = k & 3, coh = n >> 6, nt = (n >> 5) & 1, r = n & 31;
-    (void)N;
-    return (((((((size_t)coh * 16 + comp) * (K >> 5) + cc) * 4 + g) * 2 + nt) * 64) + r + 32 * h) * 4 + j;
-}
-#define WN_ZTAIL 256        // zero floats behind the packed weights: the source of the patch's zero padding (LDS-DMA cannot write a constant)
-// one thread per (co, ci): U = G g G^T for the forward (g[a][c] = w[co][ci][kh = c][kw = a]: a runs along time, c along mel) and for
-// the data gradient (contraction over co, g'[a][c] = w[co][ci][2 - c][2 - a])
 __global__ void conv_pack_wino_k(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < WN_ZTAIL) {
-        if (uf) uf[(size_t)16 * Cout * Cin + i] = 0.f;
-        if (ud) ud[(size_t)16 * Cout * Cin + i] = 0.f;
-    }
-    if (i >= Cout * Cin) return;
-    const int ci = i % Cin, co = i / Cin;
-    float g[3][3];                                   // [a = kw][c = kh]
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) g[kw][kh] = w[(size_t)i * 9 + kh * 3 + kw];
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        float* dst = pass ? ud : uf;
-        if (!dst) continue;
-        float t[4][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float g0 = pass ? g[2][2 - c] : g[0][c], g1 = pass ? g[1][2 - c] : g[1][c], g2 = pass ? g[0][2 - c] : g[2][c];
-            t[0][c] = g0;
-            t[1][c] = 0.5f * (g0 + g1 + g2);
-            t[2][c] = 0.5f * (g0 - g1 + g2);
-            t[3][c] = g2;
-        }
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), u3 = t[xi][2];
-            const float uu[4] = {u0, u1, u2, u3};
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-                dst[pass ? wino_frag_index(xi * 4 + nu, co, ci, Cout, Cin) : wino_frag_index(xi * 4 + nu, ci, co, Cin, Cout)] = uu[nu];
-        }
-    }
+    wino_pack_one(w, uf, ud, Cout, Cin, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 extern "C" size_t sed_conv3x3_wino_packed_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin + WN_ZTAIL; }
