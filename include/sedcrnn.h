@@ -87,8 +87,12 @@ int sed_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, float* dw_
  * mode | SED_WGRAD_ZERO_ROW_CLEAN: the exact-fp32 MFMA kernel reads out-of-image rows from a zero-filled row at the START of
  * the workspace (sed_conv3x3_wgrad_zero_row_bytes(), 0 for shapes that have none), which the entry clears with a memset on
  * `stream` in every call — unless this flag says the caller keeps those bytes zero (nothing ever writes them): a plan that
- * calls the entry every step clears them once, off its critical chain, and saves the memset node in front of each launch. */
+ * calls the entry every step clears them once, off its critical chain, and saves the memset node in front of each launch.
+ * mode | SED_WGRAD_DIRECT: mel extents that cut into 40- or 32-column tiles run the position-contiguous kernel in the Winograd
+ * domain by default (F(2x2,3x3): 16 products per 2x2 tile and channel pair instead of 36, dW = G^T dU G applied by the slab
+ * reduction; exact-fp32 MFMA arithmetic, see wino.hip); this flag keeps the direct 36-product form (A/B measurements, tests). */
 #define SED_WGRAD_ZERO_ROW_CLEAN 0x100
+#define SED_WGRAD_DIRECT 0x200
 size_t sed_conv3x3_wgrad_zero_row_bytes(int B, int Cin, int F, int T, int Cout);
 int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* dy, float* dw_oihw,
                          void* workspace, int B, int Cin, int F, int T, int Cout, int mode, void* stream);

@@ -1405,7 +1405,7 @@ static WgradPlan wgrad_plan(int B, int Cin, int F, int T, int Cout, int x_is_nch
     // mfma: one resident block per CU at Cin=128 (grid = ngroups x Cin/32); small (HBM-bound): enough blocks to fill every CU 4x
     const int maxg = (p.kind == 1) ? 64 : 1024;
     p.ngroups = p.ntiles < maxg ? p.ntiles : maxg;
-    p.slab_floats = (size_t)p.ngroups * 9 * Cin * Cout;
+    p.slab_floats = (size_t)p.ngroups * (p.v2 ? 16 : 9) * Cin * Cout;      // (the Winograd form of the position-contiguous kernel: 16 components)
     // the position-contiguous kernel reads rows outside the image from a zero-filled row behind the slabs
     p.zrow_floats = p.v2 ? (((size_t)(p.FT + 4) * (Cin > Cout ? Cin : Cout) + 64 + 63) / 64) * 64 : 0;      // at the START of the workspace
     return p;
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(256, MT ? 1 : 2) void conv3x3_mfma_wgrad_k(
 // registers -> four ds_write_b32; the next tile's 13-16 float4 per thread are loaded in batches two k-chunks ahead of their
 // commit, so at most two batches (32-40 VGPRs) are in flight and no load is waited for.  Row strides are an odd number of
 // 16-byte granules (conflict-free b128 reads across the 32 channel lanes).
-template <int FT>
+template <int FT, bool WINO = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, const float* __restrict__ zrow,
     int B, int Cin, int F, int T, int Cout, int nft, int tblocks, int ntiles, unsigned* __restrict__ arrive) {
@@ -1719,11 +1719,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
     static_assert(FT % 8 == 0 && PX % 4 == 0 && ((XCI / 4) & 1) == 1 && ((DCO / 4) & 1) == 1, "pitches: 16-B aligned, odd granule strides");
     constexpr int XBUF = 32 * XCI, BUF = XBUF + 128 * DCO;
     constexpr int HR = (TT + 2) * F2, MROWS = TT * FT;
-    constexpr int NCH = TT * (FT / 8);              // k-chunks (8 positions) per tile
+    constexpr int NCH = WINO ? FT / 8 : TT * (FT / 8);      // k-chunks per tile: 8 positions of a time row; WINO: 4 Winograd tiles (2 x 8 positions)
     // staging batches of the NEXT tile: batch b is loaded before the MFMAs of chunk b and committed before those of chunk
     // NCH - NB + b, i.e. NCH - NB chunks (>= 5 us of MFMA work) later: a commit that has to wait for its load stalls the MFMA
     // pipe (the wave issues in order), so the distance must cover the HBM latency under load with a wide margin
-    constexpr int NB = NCH >= 10 ? 4 : 3;
+    constexpr int NB = NCH >= 10 ? 4 : (NCH >= 6 ? 3 : 2);
     static_assert(NB >= 1 && 2 * NB <= NCH, "staging schedule");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1731,9 +1731,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 128;
     (void)HR; (void)MROWS;
 
-    f32x16 acc[9];
+    constexpr int NACC = WINO ? 16 : 9;            // WINO: [nu][channel tile] of this wave's row combination xi = wave
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < NACC; ++k)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[k][j] = 0.f;
 
@@ -1828,6 +1829,61 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
                 }
     };
 
+    // ── WINO: the weight gradient in the Winograd domain (F(2x2,3x3), see wino.hip) ──
+    // dU[xi,nu][ci][co] = sum over 2x2 output tiles of (B^T d B)[xi,nu][ci] (A dY A^T)[xi,nu][co], 16 products per tile and channel pair
+    // instead of 36; dW = G^T dU G is applied by the slab reduction.  A tile row = this kernel's tile (2 time rows, 4 halo rows); a
+    // k-chunk = 4 Winograd tiles = 8 mel columns, MFMA j takes tile 2h + j of the chunk.  Wave xi forms its own row combination of the
+    // patch (d[ra] + sg d[rb]) and of the gradient rows (y0, y0 + y1, y0 - y1, y1) and holds the four column combinations nu for all
+    // four 32-channel tiles of the workgroup's 128 output channels: 16 accumulators.  The signs of A's last row / column (-y1) are
+    // left to the reduction: the products are linear in them.  Which rows a wave combines is DATA (row offsets and a coefficient in
+    // scalar registers), not control flow: every wave runs the same straight-line chunk (y[ya] + ys y[yb], ys = 0 for the plain rows).
+    const int w_ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1), w_rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float w_sg = wave == 1 ? 1.f : -1.f;
+    const int w_ya = wave == 3 ? FT : 0, w_yb = wave == 0 ? 0 : FT;
+    const float w_ys = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+    struct WOps { f32x4 a[2]; f32x2 a2[2]; f32x4 b[4][2]; };
+    auto wfetch = [&](const float* buf, int kc, WOps& o) {
+        const float* xp = buf + r * XCI + kc * 8 + 4 * h;
+        o.a[0] = *(const f32x4*)(xp + w_ra * PX);
+        o.a2[0] = *(const f32x2*)(xp + w_ra * PX + 4);
+        o.a[1] = *(const f32x4*)(xp + w_rb * PX);
+        o.a2[1] = *(const f32x2*)(xp + w_rb * PX + 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float* dp = buf + XBUF + (nt * 32 + r) * DCO + kc * 8 + 4 * h;
+            o.b[nt][0] = *(const f32x4*)(dp + w_ya);
+            o.b[nt][1] = *(const f32x4*)(dp + w_yb);
+        }
+    };
+    auto wmfma = [&](const WOps& o) {
+        float u[6];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = o.a[0][c] + w_sg * o.a[1][c];
+        u[4] = o.a2[0][0] + w_sg * o.a2[1][0];
+        u[5] = o.a2[0][1] + w_sg * o.a2[1][1];
+        float v[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            v[j][0] = u[2 * j] - u[2 * j + 2];
+            v[j][1] = u[2 * j + 1] + u[2 * j + 2];
+            v[j][2] = u[2 * j + 2] - u[2 * j + 1];
+            v[j][3] = u[2 * j + 1] - u[2 * j + 3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            // this wave's combination of the two gradient rows: columns (c0, c1) of tile 2h, (c0, c1) of tile 2h + 1
+            const f32x4 yr = o.b[nt][0] + w_ys * o.b[nt][1];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float c0 = yr[2 * j], c1 = yr[2 * j + 1];
+                const float z[4] = {c0, c0 + c1, c0 - c1, c1};
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+                    acc[nu * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][nu], z[nu], acc[nu * 4 + nt], 0, 0, 0);
+            }
+        }
+    };
+
     constexpr int BS = (NS + NB - 1) / NB;
     // a group walks a CONTIGUOUS run of tiles (consecutive time rows of one sequence): the two halo rows a tile shares with its
     // predecessor were read by this very CU one tile earlier and come from L2 instead of HBM (a strided walk handed neighbouring
@@ -1848,6 +1904,31 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
         origin(nxt < tend ? nxt : tile);            // the last tile re-stages itself (nobody reads that image): no branch
         const float* buf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;       // last read before the previous barrier
+        if (WINO) {
+            WOps w0, w1;
+            wfetch(buf, 0, w0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                WOps& oc = (c & 1) ? w1 : w0;
+                WOps& on = (c & 1) ? w0 : w1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < NCH) wfetch(buf, c + 1, on);
+                if (c < NB) {
+#pragma unroll
+                    for (int k = c * BS; k < (c + 1) * BS && k < NS; ++k) load_item(k);
+                }
+                if (c >= NCH - NB) {
+#pragma unroll
+                    for (int k = (c - (NCH - NB)) * BS; k < (c - (NCH - NB) + 1) * BS && k < NS; ++k) commit_item(k, nbuf);
+                }
+                wmfma(oc);
+#pragma unroll
+                for (int g = 0; g < 32; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x322, 3, 0);      // up to three of: VALU, VMEM read, DS read, DS write
+                }
+            }
+        } else {
         // one tile: NCH chunks of 36 MFMAs; the staging of the next tile rides along (loads before chunks 0..NB-1, commits
         // before chunks NCH-NB..NCH-1)
         Ops o0, o1;
@@ -1880,9 +1961,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         cur ^= 1;
+    }
+    if (WINO) {                                       // slabs [group][16 components][Cin][Cout]
+        float* sl = slabs + (size_t)blockIdx.x * 16 * Cin * Cout;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    sl[((size_t)(wave * 4 + nu) * Cin + ci0 + row) * Cout + co0 + nt * 32 + r] = acc[nu * 4 + nt][j];
+                }
+        return;
     }
     float* sl = slabs + (size_t)blockIdx.x * 9 * Cin * Cout;
 #pragma unroll
@@ -2070,6 +2165,37 @@ __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float*
     dw[((size_t)co * Cin + ci) * 9 + tap] = a;
 }
 
+// Winograd slabs: dU[xi][nu] = s_xi s_nu sum_g slabs[g][xi*4+nu][ci][co] (s_3 = -1: the sign of A's last row, see the kernel), then
+// dW = G^T dU G with G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; the first index of dU runs along time (kw), the second along mel (kh)
+__global__ void conv_wgrad_reduce_wino_k(const float* __restrict__ slabs, float* __restrict__ dw, int ngroups, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = Cin * Cout;
+    if (i >= n) return;
+    const int co = i % Cout, ci = i / Cout;
+    float U[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float a = 0.f;
+#pragma unroll 8
+        for (int g = 0; g < ngroups; ++g) a += slabs[((size_t)g * 16 + k) * n + i];
+        U[k >> 2][k & 3] = (((k >> 2) == 3) != ((k & 3) == 3)) ? -a : a;
+    }
+    float t[3][4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+        t[0][nu] = U[0][nu] + 0.5f * (U[1][nu] + U[2][nu]);
+        t[1][nu] = 0.5f * (U[1][nu] - U[2][nu]);
+        t[2][nu] = U[3][nu] + 0.5f * (U[1][nu] + U[2][nu]);
+    }
+    float* o = dw + ((size_t)co * Cin + ci) * 9;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        o[0 * 3 + kw] = t[kw][0] + 0.5f * (t[kw][1] + t[kw][2]);
+        o[1 * 3 + kw] = 0.5f * (t[kw][1] - t[kw][2]);
+        o[2 * 3 + kw] = t[kw][3] + 0.5f * (t[kw][1] + t[kw][2]);
+    }
+}
+
 extern "C" size_t sed_conv3x3_wgrad_zero_row_bytes(int B, int Cin, int F, int T, int Cout) {
     if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
     return wgrad_plan(B, Cin, F, T, Cout, 0, 0).zrow_floats * sizeof(float);
@@ -2089,7 +2215,7 @@ extern "C" int sed_conv3x3_wgrad_ex(const float* x, int x_is_nchw, const float* 
 // and each announces itself on `arrive`); 0 for the shapes / modes whose kernel does not announce
 int sed_internal_conv3x3_wgrad_workgroups(int B, int Cin, int F, int T, int Cout, int x_is_nchw, int mode) {
     if (B <= 0 || Cin <= 0 || F <= 0 || T <= 0 || Cout <= 0 || Cout % 4 != 0) return 0;
-    mode &= ~SED_WGRAD_ZERO_ROW_CLEAN;
+    mode &= ~(SED_WGRAD_ZERO_ROW_CLEAN | SED_WGRAD_DIRECT);
     if (mode != 0) return 0;
     const WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
     return p.kind == 1 ? p.ngroups * (Cin / 32) * (Cout / 128) : 0;
@@ -2099,7 +2225,8 @@ int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, f
                                int B, int Cin, int F, int T, int Cout, int mode, unsigned* arrive, void* stream) {
     SED_REQUIRE(x && dy && dw && workspace, "conv3x3_wgrad: null pointer");
     const bool zero_row_clean = (mode & SED_WGRAD_ZERO_ROW_CLEAN) != 0;      // the caller cleared sed_conv3x3_wgrad_zero_row_bytes()
-    mode &= ~SED_WGRAD_ZERO_ROW_CLEAN;
+    const bool direct = (mode & SED_WGRAD_DIRECT) != 0;                      // the 36-product kernel instead of the Winograd form
+    mode &= ~(SED_WGRAD_ZERO_ROW_CLEAN | SED_WGRAD_DIRECT);
     SED_REQUIRE(mode == 0 || mode == 1, "conv3x3_wgrad: unknown mode %d", mode);
     SED_REQUIRE(Cout % 4 == 0, "conv3x3_wgrad: Cout must be a multiple of 4 (got %d)", Cout);
     WgradPlan p = wgrad_plan(B, Cin, F, T, Cout, x_is_nchw, mode);
@@ -2129,15 +2256,27 @@ int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, f
             hipError_t e = hipMemsetAsync(zrow, 0, p.zrow_floats * sizeof(float), s);
             if (e != hipSuccess) { sed_set_error("conv3x3_wgrad: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
         }
-        if (p.FT == 40) {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<40>, p.lds));
-            conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+        if (!direct) {
+            if (p.FT == 40) {
+                SED_TRY(set_lds((conv3x3_mfma_wgrad2_k<40, true>), p.lds));
+                conv3x3_mfma_wgrad2_k<40, true><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+            } else {
+                SED_TRY(set_lds((conv3x3_mfma_wgrad2_k<32, true>), p.lds));
+                conv3x3_mfma_wgrad2_k<32, true><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+            }
+            SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2 (Winograd)");
+            conv_wgrad_reduce_wino_k<<<cdiv(Cin * Cout, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
         } else {
-            SED_TRY(set_lds(conv3x3_mfma_wgrad2_k<32>, p.lds));
-            conv3x3_mfma_wgrad2_k<32><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+            if (p.FT == 40) {
+                SED_TRY(set_lds((conv3x3_mfma_wgrad2_k<40>), p.lds));
+                conv3x3_mfma_wgrad2_k<40><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+            } else {
+                SED_TRY(set_lds((conv3x3_mfma_wgrad2_k<32>), p.lds));
+                conv3x3_mfma_wgrad2_k<32><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
+            }
+            SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2");
+            conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
         }
-        SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2");
-        conv_wgrad_reduce_mfma_k<<<cdiv(n, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
     } else if (p.kind == 1) {
         dim3 grid(p.ngroups, Cin / 32, Cout / 128);
         if (p.nft == 1) {

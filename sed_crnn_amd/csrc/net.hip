@@ -623,7 +623,7 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     // The auxiliary stream is FORKED from the main stream first (event record + wait): under hipGraph capture that is what
     // makes it part of the capture, so the memsets are graph nodes and every replay clears the rows again (round-3 advisor:
     // issued on the un-forked stream they ran once, outside the graph, and every replay trusted bytes nobody re-cleared).
-    const int wg_clean = (L.wgrad_zrow > 0 && s_aux) ? SED_WGRAD_ZERO_ROW_CLEAN : 0;
+    const int wg_clean = ((L.wgrad_zrow > 0 && s_aux) ? SED_WGRAD_ZERO_ROW_CLEAN : 0) | ((c->flags & SED_NET_DIRECT_CONV) ? SED_WGRAD_DIRECT : 0);
     if (s_aux && stage_begin == 0 && L.n_conv > 1) {
         hipError_t e = hipEventRecord(ev_gru[SED_MAX_GRU + 4], s_main);
         if (e == hipSuccess) e = hipStreamWaitEvent(s_aux, ev_gru[SED_MAX_GRU + 4], 0);
