@@ -36,13 +36,17 @@ WORKLOAD = dict(B=128, Cin=1, F=40, T=256, C=128, H=128, gru_layers=2, dropout=0
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (= fp32 vector peak)
 PROFILE_ROUNDS = ("r4", "r3", "r2", "r1")   # newest committed PMC summary first
 
-# the dominant kernel: conv2 / conv3 forward (<4, 2, false>) and their data gradients (<4, 2, true>: the same main loop with the
-# BatchNorm-backward reduction of the block below in its epilogue); one in-library timer tag covers both
-DOMINANT_KERNEL = "conv3x3_mfma_fwd2_k"
-DOMINANT_PREFIX = "void conv3x3_mfma_fwd2_k<4, 2"      # every instantiation of the 128-channel tile: forward, data gradient (+ fused sums)
+# the dominant kernel: conv2 / conv3 forward (<14, false>) and their data gradients (<14, true, *>: the same main loop with the
+# BatchNorm-backward reduction of the block below in its epilogue); one in-library timer tag covers both.  Since round 4 it is the
+# Winograd F(2x2,3x3) form (wino.hip): 16 MFMA products per 36 algorithmic multiply-adds.  --direct-conv runs the direct kernels.
+DOMINANT_KERNEL = "conv3x3_wino_k"
+DOMINANT_PREFIX = "void conv3x3_wino_k<14"             # every instantiation: forward, data gradient (+ fused sums)
+DIRECT_KERNEL = "conv3x3_mfma_fwd2_k"
+DIRECT_PREFIX = "void conv3x3_mfma_fwd2_k<4, 2"
+WINO_EXECUTED = 16.0 / 36.0                            # executed / algorithmic multiply-adds of F(2x2, 3x3)
 
 
-def pmc_traffic_bytes():
+def pmc_traffic_bytes(prefix=None):
     """HBM traffic per launch of the dominant kernel, from the committed PMC summary (collected as the
     MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE in separate --pmc passes; FETCH_SIZE counts half of a wide
     coalesced read on gfx950, verified here on the pure-streaming bn kernel), launch-weighted over the kernel's
@@ -55,7 +59,7 @@ def pmc_traffic_bytes():
             continue
         tot, n = 0.0, 0
         for name, e in d.items():
-            if name.startswith(DOMINANT_PREFIX) and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:
+            if name.startswith(prefix or DOMINANT_PREFIX) and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:
                 k = int(e.get("launches", 1))
                 tot += k * (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024
                 n += k
@@ -284,6 +288,8 @@ def run_rank(args):
     y = (torch.rand(w["B"], w["T"] // 8, 1, generator=g) > 0.8).float().to(dev)
     if args.conv_bf16x3:
         model.set_conv_precision("bf16x3")
+    if args.direct_conv:
+        model.plan_flags = 0x4                               # SED_NET_DIRECT_CONV: the 36-product kernels (A/B against the Winograd default)
     step = FusedTrainStep(model, lr=1e-3, loss="bce")
     for _ in range(args.warmup):
         step.step(x, y)
@@ -427,9 +433,11 @@ def run_rank(args):
         if n.value:
             avg_ms = ms.value / n.value
             tf = units.value / (ms.value * 1e-3) / 1e12
-            traffic, rnd = pmc_traffic_bytes()
+            wino = not args.conv_bf16x3 and not args.direct_conv
+            traffic, rnd = pmc_traffic_bytes(None if wino else DIRECT_PREFIX)
             peak = F32_MFMA_PEAK_TFLOPS if not args.conv_bf16x3 else 2500.0 / 3.0      # 3 bf16 MFMA flops per algorithmic flop
-            kname = DOMINANT_KERNEL + "<4, 2, *>" if not args.conv_bf16x3 else "conv3x3_mfma_fwd_bf16x3_k<4, 2>"
+            kname = (DOMINANT_KERNEL + "<14, *> (Winograd F(2x2,3x3), exact-fp32 MFMA)" if wino else
+                     DIRECT_KERNEL + "<4, 2, *>" if not args.conv_bf16x3 else "conv3x3_mfma_fwd_bf16x3_k<4, 2>")
             if args.conv_bf16x3:
                 traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": kname + " (conv2/conv3 forward + their data gradients)",
@@ -442,14 +450,20 @@ def run_rank(args):
                                "flops_per_launch_avg": units.value / n.value,
                                "measured_over": f"hipEvent pairs on the launch stream around every launch of this kernel in {args.steps} "
                                                 "fit steps identical to, and run right after, the timed region (ms_per_step_instrumented)"}
+            if wino:
+                out["roofline"]["executed"] = {
+                    "achieved": round(tf * WINO_EXECUTED, 2), "frac": round(tf * WINO_EXECUTED / peak, 4), "unit": "TFLOP/s",
+                    "note": "`achieved` / `frac` above are ALGORITHMIC flops (2 x 9 x Cin x Cout per output position, SURVEY 8(d)) per second "
+                            "against the fp32 MFMA peak, as the contract defines them; the Winograd form executes 16/36 of them on the "
+                            "matrix cores, so frac > 1 is the algorithm's gain and THIS object is the MFMA pipe's own utilisation"}
             if n_f.value and n_d.value:
                 def _inst(ms_i, n_i, u_i):
                     tf_i = u_i.value / (ms_i.value * 1e-3) / 1e12
                     return {"achieved": round(tf_i, 2), "frac": round(tf_i / peak, 4), "avg_launch_ms": round(ms_i.value / n_i.value, 4),
                             "launches": n_i.value}
                 out["roofline"]["in_step_by_instantiation"] = {
-                    "forward <4, 2, false>": _inst(ms_f, n_f, units_f),
-                    "data gradient + BatchNorm-backward sums <4, 2, true>": _inst(ms_d, n_d, units_d),
+                    "forward": _inst(ms_f, n_f, units_f),
+                    "data gradient + BatchNorm-backward sums": _inst(ms_d, n_d, units_d),
                     "note": "the forward launches have the GPU to themselves inside the step; the data gradient of conv2 runs while the "
                             "top block's weight-gradient kernel (auxiliary stream) holds part of the CUs, so its event pair spans the "
                             "work of both kernels: `frac` above averages over all four launches per step as the contract asks"}
@@ -477,6 +491,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--direct-conv", action="store_true", help="A/B: the direct 36-product conv kernels instead of the Winograd default")
     ap.add_argument("--breakdown", action="store_true", help="per-kernel-family times of 2 extra steps on stderr")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="exercise launch + rendezvous + staged all-reduce without the HIP kernels (CPU tests); not a benchmark")

@@ -139,6 +139,9 @@ int sed_conv3x3_dgrad_bnred(const float* dy, const float* wp_dgrad, float* dx, f
  * its zero padding from); either may be NULL.
  * wino_fwd = sed_conv3x3_fwd on channels-last x; wino_dgrad_bnred = sed_conv3x3_dgrad_bnred (same arguments and outputs). */
 int sed_conv3x3_wino_rows(int B, int Cin, int F, int T, int Cout);
+/* measurement only (tools/kprobe.py): buf = 4 device uint64 — prologue / main loop / epilogue ticks of the 100 MHz clock summed
+ * over the workgroups of every following Winograd forward / data-gradient launch, and the workgroup count; NULL switches it off. */
+int sed_conv3x3_wino_phase_ticks(unsigned long long* buf);
 size_t sed_conv3x3_wino_packed_floats(int Cout, int Cin);
 int sed_conv3x3_wino_pack_weights(const float* w_oihw, float* uf, float* ud, int Cout, int Cin, void* stream);
 int sed_conv3x3_wino_fwd(const float* x, const float* uf, const float* bias, float* y, float* stat_partials,
@@ -147,6 +150,12 @@ int sed_conv3x3_wino_dgrad_bnred(const float* dy, const float* ud, float* dx, fl
                                  const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                                  const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                                  int B, int C, int F, int T, int Cin, void* stream);
+/* = sed_conv3x3_dgrad_bnred_rg (the first block's weight-gradient sums from the same epilogue); rows = sed_conv3x3_wino_rg_rows() */
+int sed_conv3x3_wino_rg_rows(int B, int C, int F, int T, int Cin, int Cin1);
+int sed_conv3x3_wino_dgrad_bnred_rg(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,
+                                    const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
+                                    const float* x1, int Cin1, const unsigned char* argmax_bits, float* rg_partials,
+                                    int B, int C, int F, int T, int Cin, void* stream);
 /* The same launch when the block below is the recomputed first block with Cin1 = 1 or 2 input channels and pool (1,2)
  * (sed.py:86-92, ch = 1 or 2): the epilogue also forms that block's weight-gradient sums — rg_partials [rows][Cin][1 + 9 Cin1]
  * = (sum g, R_k) per channel and workgroup, R_{(3kh+kw) Cin1 + ci} = sum g~ x[ci][f+kh-1][2t'+sel+kw-1] with sel the arg-max

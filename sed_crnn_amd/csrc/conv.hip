@@ -2167,25 +2167,36 @@ __global__ void conv_wgrad_reduce_mfma_k(const float* __restrict__ slabs, float*
 
 // Winograd slabs: dU[xi][nu] = s_xi s_nu sum_g slabs[g][xi*4+nu][ci][co] (s_3 = -1: the sign of A's last row, see the kernel), then
 // dW = G^T dU G with G = [[1,0,0],[1/2,1/2,1/2],[1/2,-1/2,1/2],[0,0,1]]; the first index of dU runs along time (kw), the second along mel (kh)
-__global__ void conv_wgrad_reduce_wino_k(const float* __restrict__ slabs, float* __restrict__ dw, int ngroups, int Cin, int Cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_wino_k(const float* __restrict__ slabs, float* __restrict__ dw, int ngroups, int Cin, int Cout) {
+    // a workgroup: 64 consecutive (ci, co) pairs x 16 components, wave k = component k: every load instruction is one coalesced
+    // 256-byte piece, and a thread keeps 8 of them in flight (a one-load-at-a-time chain per thread ran this pass at 1 TB/s);
+    // the components meet in LDS and the first wave applies the two 4 -> 3 transforms
+    __shared__ float U[16][64];
     const int n = Cin * Cout;
-    if (i >= n) return;
-    const int co = i % Cout, ci = i / Cout;
-    float U[4][4];
+    const int il = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    if (i < n) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* sp = slabs + (size_t)k * n + i;
+        int g = 0;
+        for (; g + 8 <= ngroups; g += 8) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float a = 0.f;
-#pragma unroll 8
-        for (int g = 0; g < ngroups; ++g) a += slabs[((size_t)g * 16 + k) * n + i];
-        U[k >> 2][k & 3] = (((k >> 2) == 3) != ((k & 3) == 3)) ? -a : a;
+            for (int e = 0; e < 8; ++e) a[e] += sp[(size_t)(g + e) * 16 * n];
+        }
+        for (; g < ngroups; ++g) a[0] += sp[(size_t)g * 16 * n];
+        const float t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        U[k][il] = (((k >> 2) == 3) != ((k & 3) == 3)) ? -t : t;
     }
+    __syncthreads();
+    if (threadIdx.x >= 64 || i >= n) return;
+    const int co = i % Cout, ci = i / Cout;
     float t[3][4];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) {
-        t[0][nu] = U[0][nu] + 0.5f * (U[1][nu] + U[2][nu]);
-        t[1][nu] = 0.5f * (U[1][nu] - U[2][nu]);
-        t[2][nu] = U[3][nu] + 0.5f * (U[1][nu] + U[2][nu]);
+        const float u0 = U[nu][il], u1 = U[4 + nu][il], u2 = U[8 + nu][il], u3 = U[12 + nu][il];
+        t[0][nu] = u0 + 0.5f * (u1 + u2);
+        t[1][nu] = 0.5f * (u1 - u2);
+        t[2][nu] = u3 + 0.5f * (u1 + u2);
     }
     float* o = dw + ((size_t)co * Cin + ci) * 9;
 #pragma unroll
@@ -2265,7 +2276,7 @@ int sed_internal_conv3x3_wgrad(const float* x, int x_is_nchw, const float* dy, f
                 conv3x3_mfma_wgrad2_k<32, true><<<grid, 256, p.lds, s>>>(x, dy, slabs, zrow, B, Cin, F, T, Cout, p.nft, p.tblocks, p.ntiles, arrive);
             }
             SED_LAUNCH_CHECK("conv3x3_mfma_wgrad2 (Winograd)");
-            conv_wgrad_reduce_wino_k<<<cdiv(Cin * Cout, 256), 256, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
+            conv_wgrad_reduce_wino_k<<<cdiv(Cin * Cout, 64), 1024, 0, s>>>(slabs, dw, p.ngroups, Cin, Cout);
         } else {
             if (p.FT == 40) {
                 SED_TRY(set_lds((conv3x3_mfma_wgrad2_k<40>), p.lds));

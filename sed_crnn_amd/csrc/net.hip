@@ -139,8 +139,9 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         if (rr > max_bn_rows) max_bn_rows = rr;
         // ... and, for the recomputed first block with 1 or 2 input channels, its weight-gradient sums too (1 + 9 Cin floats per
         // channel and workgroup)
-        if (l == 1 && rr > 0 && !q.wino_d && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin <= 2) {
-            const int gr = sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin, L->cv[0].Cin);
+        if (l == 1 && rr > 0 && L->cv[0].fused && L->cv[0].rgrad && L->cv[0].Cin <= 2) {
+            const int gr = q.wino_d ? sed_conv3x3_wino_rg_rows(c->B, q.C, q.F, q.T, q.Cin, L->cv[0].Cin)
+                                    : sed_conv3x3_dgrad_bnred_rg_rows(c->B, q.C, q.F, q.T, q.Cin, L->cv[0].Cin);
             L->cv[0].rg_rows = gr;
             const size_t need = (size_t)gr * q.Cin * (1 + 9 * L->cv[0].Cin);
             if (need > c1_ws) c1_ws = need;
@@ -549,6 +550,10 @@ static int bn_backward(const Layout& L, const sed_net_cfg* c, const sed_net_para
 static int dgrad(const Layout& L, const sed_net_cfg* c, const sed_net_params* p, const float* x, float* ws, int l, void* st) {
     const ConvL& q = L.cv[l];
     const ConvL& u = L.cv[l - 1];
+    if (u.rg_rows > 0 && q.wino_d)
+        return sed_conv3x3_wino_dgrad_bnred_rg(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
+                                               p->bn_g[l - 1], p->bn_b[l - 1], ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop,
+                                               x, u.Cin, (const unsigned char*)(ws + L.c1_bits), ws + L.c1_ws, c->B, q.C, q.F, q.T, q.Cin, st);
     if (u.rg_rows > 0)
         return sed_conv3x3_dgrad_bnred_rg(ws + L.dconv[l], ws + L.wp_d[l], ws + L.gradA, ws + L.bn_part, ws + L.pooled[l - 1],
                                           p->bn_g[l - 1], p->bn_b[l - 1], ws + L.mean[l - 1], ws + L.rstd[l - 1], u.drop,
@@ -735,7 +740,12 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
     const int top = L.n_conv - 1;
     // the top block's weight gradient runs on the auxiliary stream (decided by the configuration alone: the stages of one
     // backward may arrive in separate calls)
-    const bool top_wgrad_on_aux = s_aux && top > 1;
+    // Only the direct kernels: the Winograd kernels (one wave per SIMD, 430-460 registers, 130 KB of LDS) share a CU with nothing of
+    // their own size and lose more to a co-running vector pass than that pass gains (config 2: the top block's weight gradient
+    // beside the BatchNorm apply pass of the block below took 806 us for both, one after the other 418 + 164) — there the top
+    // block's weight gradient follows that pass on the main stream.
+    const bool top_wgrad_on_aux = s_aux && top > 1 && (c->flags & SED_NET_DIRECT_CONV);
+    const bool top_wgrad_in_stage = s_aux && top > 1 && !top_wgrad_on_aux;
     for (int s = (stage_begin > 1 ? stage_begin : 1); s < stage_end; ++s) {
         const int l = L.n_conv - s;
         const ConvL& q = L.cv[l];
@@ -765,15 +775,17 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
                 (void)hipEventRecord(ev_gru[SED_MAX_GRU + 2], s_aux);
             }
             SED_TRY(bn_passes(l - 1, stream));
+            if (top_wgrad_in_stage && l == top) SED_TRY(wgrad(l));      // (its gradients are part of this stage's bucket, as on the auxiliary stream)
             continue;
         }
         // the deferred MFMA weight gradients, main stream (the top block's runs on the auxiliary stream since its own stage)
         int first_wg = 0;
         for (int k = top; k >= 1 && !first_wg; --k)
-            if (!(k == top && top_wgrad_on_aux)) first_wg = k;
+            if (!(k == top && (top_wgrad_on_aux || top_wgrad_in_stage))) first_wg = k;
         unsigned* arrive = nullptr;
         unsigned gate_target = 0;
-        if (s_aux && first_wg && !(c->flags & SED_NET_NO_GATE)) {
+        const bool co_run = s_aux && (c->flags & SED_NET_DIRECT_CONV);      // see top_wgrad_on_aux: only the direct kernels share their CUs
+        if (co_run && first_wg && !(c->flags & SED_NET_NO_GATE)) {
             const ConvL& w = L.cv[first_wg];
             int n = sed_internal_conv3x3_wgrad_workgroups(B, w.Cin, w.F, w.T, w.C, w.nchw, c->conv_mode);
             static thread_local int n_cu[kMaxDev] = {};
@@ -788,14 +800,22 @@ extern "C" int sed_net_backward(const sed_net_cfg* c, const sed_net_params* p, c
         }
         auto main_wgrads = [&]() -> int {
             for (int k = top; k >= 1; --k) {
-                if (k == top && top_wgrad_on_aux) continue;
+                if (k == top && (top_wgrad_on_aux || top_wgrad_in_stage)) continue;
                 const ConvL& w = L.cv[k];
                 SED_TRY(sed_internal_conv3x3_wgrad(ws + L.pooled[k - 1], w.nchw, ws + L.dconv[k], g->conv_w[k], ws + L.wgrad_ws, B, w.Cin, w.F, w.T, w.C,
                                                    c->conv_mode | wg_clean, k == first_wg ? arrive : nullptr, stream));
             }
             return 0;
         };
-        if (s_aux) {
+        if (s_aux && !co_run) {
+            // Winograd kernels: the first block's passes run BEFORE the weight gradients on the main stream (config 2: the 30 us
+            // assembly kernel, released beside the weight gradient, found no CU for 0.9 ms and then shared the tail with the slab
+            // reduction: both took 110 us)
+            SED_TRY(bn_passes(0, stream));
+            if (wg0_with_bn) SED_TRY(wgrad_on(0, stream));
+            SED_TRY(main_wgrads());
+            (void)hipEventRecord(ev_bn[0], s_main);
+        } else if (s_aux) {
             // block 0's sums came out of the data gradient just issued: finalising them is one tiny launch (16 workgroups, 10 us
             // alone) that took 0.1-0.33 ms when it started the auxiliary chain BESIDE the MFMA weight gradient; on the main
             // stream, before that kernel is issued, it costs its 10 us and the apply pass starts at once

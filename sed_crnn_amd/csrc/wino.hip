@@ -42,6 +42,7 @@ struct WinoGeo {
     int Fw, Tw, ntile, nblk, TR, F2, H2, HR, nb8, ncoh, NH;
     float invFw, invF2;
     size_t lds;
+    unsigned long long* dbg;      // measurement only (sed_conv3x3_wino_phase_ticks): per-phase s_memrealtime sums, NULL in production
 };
 
 // ───────────────────────── weight transform + packing ─────────────────────────
@@ -78,7 +79,8 @@ static bool wino_geo(int B, int Cin, int F, int T, int Cout, WinoGeo* g) {
     // statistics exchange reuse them; the row table behind
     size_t fl = (size_t)2 * g->NH * 1024;
     if (fl < 32768 + 512) fl = 32768 + 512;
-    g->lds = (fl + 64) * sizeof(float);
+    g->lds = (fl + 64) * sizeof(float);              // + the row table
+    g->dbg = nullptr;
     return g->lds <= 160 * 1024;
 }
 
@@ -88,15 +90,22 @@ int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
 }
 
 // ───────────────────────── the kernel ─────────────────────────
-template <int NH, bool BNR>
+// RGC > 0 (data gradient of the block above the recomputed first block with RGC input channels, pool (1,2)): the epilogue also forms
+// that block's weight-gradient sums R_k from the gradient values in registers, exactly as the direct kernel's RG epilogue does
+// (conv.hip): the network input under the block's tile rows is held in LDS, the arg-max bits pick the time row.
+template <int NH, bool BNR, int RGC = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     const float* __restrict__ x, const float* __restrict__ uq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, WinoGeo geo, ConvBnRed br) {
     constexpr int CIN = WN_CIN, NCHUNK = CIN / 32, NSTEP = 4 * NCHUNK;
     constexpr int HBUF = NH * 1024;                       // floats per patch buffer (NH KiB per wave)
+    constexpr bool RG = RGC > 0;
+    static_assert(!RG || BNR, "the tap sums belong to the BatchNorm-backward epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
+    if (geo.dbg) tk0 = __builtin_amdgcn_s_memrealtime();
 
     // workgroup -> (sequence, tile block, channel half).  Workgroups are dealt round-robin to the 8 XCDs in launch order: the
     // channel halves of a block and the blocks of a sequence are given to the same XCD (they share the input patch through its L2)
@@ -163,10 +172,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 
     // the epilogue's table: byte offset of output position (2 ty, 2 tf), channel 0, inside sequence b; ~0: no such tile
     unsigned* rowtab = (unsigned*)(smem + (2 * HBUF > 32768 + 512 ? 2 * HBUF : 32768 + 512));
+    // RG: a second table (where the tile's 3 x 4 input windows start in xs) and xs itself, the (F + 2) x (4 TR + 2) patch of the
+    // network input under this block's tile rows (time fastest, zero outside the input), one plane per input channel
+    unsigned* xofftab = rowtab + 64;
+    float* xs = (float*)(xofftab + 64);
+    const int XT = 4 * geo.TR + 2;
     if (tid < 64) {
         const int q = q0 + tid;
         const int ty = sed_fdiv(q < ntile ? q : 0, geo.invFw), tf = q - ty * Fw;
         rowtab[tid] = q < ntile ? (unsigned)(((2 * ty) * F + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
+        if (RG) xofftab[tid] = (unsigned)(2 * tf * XT + 4 * (ty - ty0));
+    }
+    if (RG) {
+        for (int i = tid; i < F2 * XT; i += 256) {
+            const int ff = i / XT, tt = i - ff * XT;
+            const int f = ff - 1, t = 4 * ty0 - 1 + tt;
+            const bool in = f >= 0 && f < F && t >= 0 && t < br.Ty;
+#pragma unroll
+            for (int ci = 0; ci < RGC; ++ci)
+                xs[ci * F2 * XT + i] = in ? br.x1[(((size_t)b * RGC + ci) * F + f) * br.Ty + t] : 0.f;
+        }
     }
 
     f32x16 acc[4][2][2];
@@ -209,6 +234,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     for (int nu = 0; nu < 4; ++nu) load_b(nu, 0);
     __syncthreads();                                   // drains the DMA (vmcnt)
     read_a(smem, 0, va[0]);
+    if (geo.dbg) tk1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int cc = st >> 2, g = st & 3, par = st & 1;
@@ -241,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         if (g == 2 && more) __syncthreads();           // the next slice's patch is complete (DMA drained) and visible
     }
     __syncthreads();                                   // every wave has read its last operands: the patch buffers are free
+    if (geo.dbg) tk2 = __builtin_amdgcn_s_memrealtime();
 
     // ── output transform ──
     // along nu in registers: Z_j = (M0 + M1 + M2, M1 - M2 - M3); each wave parks its Z[xi][j][mt][nt] as a transposed 32 x 32 tile
@@ -281,11 +308,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         }
     }
     const unsigned rstride = (unsigned)(F * Cout) * 4u, cstride = (unsigned)Cout * 4u;
+    f32x4 R[RG ? 9 * RGC : 1];
+#pragma unroll
+    for (int k = 0; k < (RG ? 9 * RGC : 1); ++k) R[k] = (f32x4){0, 0, 0, 0};
+    const unsigned char* const bitq = RG ? br.bits + (size_t)b * T * F * (Cout >> 2) + (cb >> 2) : nullptr;
+    // BNR: the pooled values (and RG: the arg-max bytes) of a row's four output positions are requested one row ahead of their
+    // use — one dependent global load per position inside the loop below cost 8 us per workgroup
+    unsigned rov[4], xov[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rov[k] = rowtab[mt * 32 + rq + 8 * k];
+        xov[k] = RG ? xofftab[mt * 32 + rq + 8 * k] : 0u;
+    }
+    f32x4 pqv[2][BNR ? 4 : 1];
+    unsigned btv[2][RG ? 4 : 1];
+    auto prefetch = [&](int k, f32x4* pqd, unsigned* btd) {
+        if (!BNR) return;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned off = rov[k] + i * rstride + jj * cstride;
+                pqd[jj * 2 + i] = (f32x4){0, 0, 0, 0};
+                if (RG) btd[jj * 2 + i] = 0u;
+                if (rov[k] != 0xFFFFFFFFu) {
+                    pqd[jj * 2 + i] = *(const f32x4*)(qb + off);
+                    if (RG) btd[jj * 2 + i] = bitq[off >> 4];
+                }
+            }
+    };
+    prefetch(0, pqv[0], btv[0]);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int m = rq + 8 * k;
-        const unsigned ro = rowtab[mt * 32 + m];
+        const unsigned ro = rov[k];
+        if (k + 1 < 4) prefetch(k + 1, pqv[(k + 1) & 1], btv[(k + 1) & 1]);
         if (ro == 0xFFFFFFFFu) continue;
+        const unsigned xo = xov[k];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             f32x4 z[4];
@@ -298,12 +357,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
                 const f32x4 v = o[i];
                 *(f32x4*)(yb + off) = v;
                 if (BNR) {
-                    const f32x4 pq = *(const f32x4*)(qb + off);
+                    const f32x4 pq = pqv[k & 1][jj * 2 + i];
                     f32x4 g0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g0[e] = pq[e] > 0.f ? v[e] : 0.f;
                     a1 += g0;
                     a2 += g0 * (pq * q_kr + q_nb);
+                    if (RG) {
+                        const unsigned bt = btv[k & 1][jj * 2 + i];
+                        f32x4 g1;                         // the share of the window's second time row
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) g1[e] = ((bt >> e) & 1u) ? g0[e] : 0.f;
+                        const f32x4 gA = g0 - g1;
+#pragma unroll
+                        for (int ci = 0; ci < RGC; ++ci) {
+                            const float* xb = xs + ci * F2 * XT + xo + jj * XT + 2 * i;
+#pragma unroll
+                            for (int kh = 0; kh < 3; ++kh) {
+                                const f32x2 x01 = *(const f32x2*)(xb + kh * XT), x23 = *(const f32x2*)(xb + kh * XT + 2);
+                                R[(kh * 3 + 0) * RGC + ci] += gA * x01[0] + g1 * x01[1];
+                                R[(kh * 3 + 1) * RGC + ci] += gA * x01[1] + g1 * x23[0];
+                                R[(kh * 3 + 2) * RGC + ci] += gA * x23[0] + g1 * x23[1];
+                            }
+                        }
+                    }
                 } else {
                     a1 += v;
                     a2 += v * v;
@@ -324,12 +401,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
             *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
         }
+        float* red2 = xs + RGC * F2 * XT;              // [4 waves][9 RGC][32]: this wave's 32 channels of the R_k (behind xs, which others may still read)
+        if (RG) {
+#pragma unroll
+            for (int k = 0; k < 9 * RGC; ++k) {
+                R[k] *= br.inv_keep;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) R[k][e] += __shfl_xor(R[k][e], o, 64);
+                }
+                if (lane < 8) *(f32x4*)(red2 + (wave * 9 * RGC + k) * 32 + c4) = R[k];
+            }
+        }
         __syncthreads();
+        const size_t row = (size_t)b * geo.nblk + blk;
         if (tid < 128) {
             const int which = tid >> 6, c = tid & 63, cn = c >> 5, cr = c & 31;
             const float a = red[((0 * 2 + cn) * 2 + which) * 32 + cr] + red[((1 * 2 + cn) * 2 + which) * 32 + cr];
-            stat[((size_t)b * geo.nblk + blk) * 2 * Cout + which * Cout + co0 + c] = a;
+            stat[row * 2 * Cout + which * Cout + co0 + c] = a;
         }
+        if (RG && tid < 64) {                           // channels co0 + tid: waves cn (m-tile 0) and 2 + cn (m-tile 1)
+            const int cn = tid >> 5, cr = tid & 31;
+            float* o = br.rgp + (row * Cout + co0 + tid) * (1 + 9 * RGC);
+            o[0] = red[((0 * 2 + cn) * 2 + 0) * 32 + cr] + red[((1 * 2 + cn) * 2 + 0) * 32 + cr];      // sum g (= the BatchNorm sum above)
+#pragma unroll
+            for (int k = 0; k < 9 * RGC; ++k)
+                o[1 + k] = red2[((0 * 2 + cn) * 9 * RGC + k) * 32 + cr] + red2[((1 * 2 + cn) * 9 * RGC + k) * 32 + cr];
+        }
+    }
+    if (geo.dbg && tid == 0) {
+        const unsigned long long tk3 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(geo.dbg + 0, tk1 - tk0);
+        atomicAdd(geo.dbg + 1, tk2 - tk1);
+        atomicAdd(geo.dbg + 2, tk3 - tk2);
+        atomicAdd(geo.dbg + 3, 1ull);
     }
 }
 
@@ -340,19 +446,32 @@ static int wino_set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+static unsigned long long* g_wino_dbg = nullptr;
+// measurement only: buf = 4 device uint64 (prologue, main loop, epilogue ticks of the 100 MHz clock summed over workgroups, workgroup
+// count), accumulated by every Winograd forward / data-gradient launch until reset with NULL
+extern "C" int sed_conv3x3_wino_phase_ticks(unsigned long long* buf) { g_wino_dbg = buf; return 0; }
+
 int sed_internal_wino_launch(const float* x, const float* uq, const float* bias, float* y, float* stat, const ConvBnRed* br,
                              int rgc, int B, int Cin, int F, int T, int Cout, hipStream_t s) {
     WinoGeo g;
     SED_REQUIRE(wino_geo(B, Cin, F, T, Cout, &g), "conv3x3_wino: shape B=%d Cin=%d F=%d T=%d Cout=%d is not supported (sed_conv3x3_wino_rows)", B, Cin, F, T, Cout);
-    SED_REQUIRE(rgc == 0, "conv3x3_wino: the first block's tap sums are not formed by this kernel");
+    SED_REQUIRE(rgc >= 0 && rgc <= 2 && (rgc == 0 || (br && br->x1 && br->bits && br->rgp)), "conv3x3_wino: bad tap-sum arguments");
+    g.dbg = g_wino_dbg;
+    if (rgc) {       // + the window-offset table, the input patch and the tap-sum exchange of the four waves
+        g.lds += ((size_t)64 + (size_t)rgc * (F + 2) * (4 * g.TR + 2) + (size_t)4 * 9 * rgc * 32) * sizeof(float);
+        SED_REQUIRE(g.lds <= 160 * 1024, "conv3x3_wino: the first block's input patch does not fit the LDS (F=%d)", F);
+    }
     const dim3 grid(g.nblk * g.ncoh, B);
     const ConvBnRed none{};
-#define WN_LAUNCH(NHv, BNRv)                                                                                              \
-    do {                                                                                                                   \
-        SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv>), g.lds));                                                         \
-        conv3x3_wino_k<NHv, BNRv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);       \
+#define WN_LAUNCH(NHv, BNRv, RGv)                                                                                          \
+    do {                                                                                                                      \
+        SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv, RGv>), g.lds));                                                       \
+        conv3x3_wino_k<NHv, BNRv, RGv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);     \
     } while (0)
-    if (br) WN_LAUNCH(WN_NHMAX, true); else WN_LAUNCH(WN_NHMAX, false);
+    if (rgc == 1) WN_LAUNCH(WN_NHMAX, true, 1);
+    else if (rgc == 2) WN_LAUNCH(WN_NHMAX, true, 2);
+    else if (br) WN_LAUNCH(WN_NHMAX, true, 0);
+    else WN_LAUNCH(WN_NHMAX, false, 0);
 #undef WN_LAUNCH
     SED_LAUNCH_CHECK("conv3x3_wino");
     return 0;
@@ -380,4 +499,24 @@ extern "C" int sed_conv3x3_wino_dgrad_bnred(const float* dy, const float* ud, fl
     const ConvBnRed br{pooled, gamma, beta, conv_out_below, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), pool_f, pool_t, Fy, Ty,
                        nullptr, nullptr, nullptr, 0.f};
     return sed_internal_wino_launch(dy, ud, nullptr, dx, partials, &br, 0, B, C, F, T, Cin, s);
+}
+
+// sed_conv3x3_dgrad_bnred_rg in the Winograd form; rows of rg_partials = sed_conv3x3_wino_rg_rows
+extern "C" int sed_conv3x3_wino_rg_rows(int B, int C, int F, int T, int Cin, int Cin1) {
+    WinoGeo g;
+    if (Cin1 < 1 || Cin1 > 2 || !wino_geo(B, C, F, T, Cin, &g)) return 0;
+    const size_t lds = g.lds + ((size_t)64 + (size_t)Cin1 * (F + 2) * (4 * g.TR + 2) + (size_t)4 * 9 * Cin1 * 32) * sizeof(float);
+    return lds <= 160 * 1024 ? B * g.nblk : 0;
+}
+extern "C" int sed_conv3x3_wino_dgrad_bnred_rg(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,
+                                               const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,
+                                               const float* x1, int Cin1, const unsigned char* argmax_bits, float* rg_partials,
+                                               int B, int C, int F, int T, int Cin, void* stream) {
+    SED_REQUIRE(dy && ud && dx && partials && pooled && gamma && beta && mean && rstd && x1 && argmax_bits && rg_partials, "conv3x3_wino_dgrad_bnred_rg: null pointer");
+    SED_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (Cin1 == 1 || Cin1 == 2), "conv3x3_wino_dgrad_bnred_rg: bad drop_p / input channels");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_DGRAD, s, 2.0 * 9.0 * C * Cin * (double)B * T * F);
+    const ConvBnRed br{pooled, gamma, beta, nullptr, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), 1, 2, F, 2 * T,
+                       x1, argmax_bits, rg_partials, 0.f};
+    return sed_internal_wino_launch(dy, ud, nullptr, dx, partials, &br, Cin1, B, C, F, T, Cin, s);
 }

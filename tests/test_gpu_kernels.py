@@ -460,6 +460,25 @@ def test_first_block_weight_gradient_sums_from_the_data_gradient_epilogue(ops, B
     # the conv-bias gradient in front of a BatchNorm is zero up to rounding (sum g - count * mean g): noise of the size of ulp(sum g)
     close(db_b, db_a, atol=4e-6 * float((sg_a.abs() * scale.abs()).max()) + 1e-6, rtol=1e-4)
     close(dgam_b, dgam_a, atol=2e-5 * float(dgam_a.abs().max()) + 1e-6, rtol=1e-4)
+    # the same epilogue behind the Winograd main loop (the plan's default where the shape takes it): dx to the Winograd rounding,
+    # the first block's dW / dbias / dgamma to the tolerance above
+    rows_w = L.sed_conv3x3_wino_rg_rows(B, C, F, Tp, C, cin)
+    if rows_w and Tp % 2 == 0 and F % 2 == 0:
+        _, ud2 = ops.conv3x3_wino_pack(g(w2))
+        dx_w, part_w = torch.empty(B, Tp, F, C).cuda(), torch.empty(rows_w, 2, C).cuda()
+        rgw = torch.full((rows_w, C, 1 + 9 * cin), float("nan")).cuda()
+        check(L.sed_conv3x3_wino_dgrad_bnred_rg(ptr(dyg), ptr(ud2), ptr(dx_w), ptr(part_w), ptr(pooled), ptr(gg), ptr(bg), ptr(mean), ptr(rstd), p,
+                                                ptr(xg), cin, ptr(bits), ptr(rgw), B, C, F, Tp, C, stream_ptr()), "wino_dgrad_bnred_rg")
+        sum_g, sum_gx, dgam_w, _ = (torch.empty(C).cuda() for _ in range(4))
+        check(L.sed_bn_bwd_finalize(ptr(part_w), rows_w, C, ptr(sum_g), ptr(sum_gx), ptr(dgam_w), ptr(_), stream_ptr()), "fin")
+        dw_w, db_w = torch.empty(C, cin, 3, 3).cuda(), torch.empty(C).cuda()
+        check(L.sed_conv1_bwd_wgrad_assemble(ptr(rgw), rows_w, ptr(mom), ptr(wf1), ptr(b1g), ptr(mean), ptr(rstd), ptr(scale), ptr(sum_g), ptr(sum_gx),
+                                             ptr(dw_w), ptr(db_w), B, cin, F, T, C, ptr(gg), ptr(bg), ptr(dgam_w), stream_ptr()), "assemble")
+        assert bool(torch.isfinite(rgw).all())
+        close(dx_w, dx_a, atol=2e-5 * float(dx_a.abs().mean()), rtol=1e-5)
+        close(dw_w, dw_a, atol=2e-5 * mag, rtol=1e-4)
+        close(db_w, db_a, atol=4e-6 * float((sg_a.abs() * scale.abs()).max()) + 1e-6, rtol=1e-4)
+        close(dgam_w, dgam_a, atol=2e-5 * float(dgam_a.abs().max()) + 1e-6, rtol=1e-4)
 
 
 def test_bn_eval_scale_shift(ops):
