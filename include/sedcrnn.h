@@ -150,6 +150,14 @@ int sed_conv3x3_wino_dgrad_bnred(const float* dy, const float* ud, float* dx, fl
                                  const float* gamma, const float* beta, const float* conv_out_below, const float* mean,
                                  const float* rstd, float drop_p, int pool_f, int pool_t, int Fy, int Ty,
                                  int B, int C, int F, int T, int Cin, void* stream);
+/* inference (= sed_conv3x3_pack_weights_bn_folded + sed_conv3x3_bn_relu_pool_eval): BatchNorm on running statistics folded into the
+ * transformed weights and the bias, ReLU + (1,2) time pool in the epilogue (the two time rows of a 2x2 tile are a pooling pair):
+ * pooled [B][T/2][F][Cout]; shapes as sed_conv3x3_wino_rows() > 0. */
+int sed_conv3x3_wino_pack_weights_bn_folded(const float* w_oihw, const float* bias, const float* gamma, const float* beta,
+                                            const float* running_mean, const float* running_var, float eps,
+                                            float* uf, float* bias_folded, int Cout, int Cin, void* stream);
+int sed_conv3x3_wino_bn_relu_pool_eval(const float* x, const float* uf_folded, const float* bias_folded, float* pooled,
+                                       int B, int Cin, int F, int T, int Cout, void* stream);
 /* = sed_conv3x3_dgrad_bnred_rg (the first block's weight-gradient sums from the same epilogue); rows = sed_conv3x3_wino_rg_rows() */
 int sed_conv3x3_wino_rg_rows(int B, int C, int F, int T, int Cin, int Cin1);
 int sed_conv3x3_wino_dgrad_bnred_rg(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,

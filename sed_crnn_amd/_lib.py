@@ -71,6 +71,8 @@ SIGNATURES = {
     "sed_conv3x3_wino_pack_weights": (_i, [_fp, _fp, _fp, _i, _i, _stream]),
     "sed_conv3x3_wino_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wino_dgrad_bnred": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _i, _i, _i, _i, _i, _i, _i, _i, _i, _stream]),
+    "sed_conv3x3_wino_pack_weights_bn_folded": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp, _i, _i, _stream]),
+    "sed_conv3x3_wino_bn_relu_pool_eval": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_wino_rg_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "sed_conv3x3_wino_dgrad_bnred_rg": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _fp, _i, _fp, _fp, _i, _i, _i, _i, _i, _stream]),
     "sed_conv3x3_dgrad_bnred_rg_rows": (_i, [_i, _i, _i, _i, _i, _i]),

@@ -57,7 +57,7 @@ int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf,
 int sed_internal_conv_pack_eval(int n, const float* const* w, const float* const* bias, const float* const* gamma,
                                 const float* const* beta, const float* const* rm, const float* const* rv, float eps,
                                 float* const* wf, float* const* scale, float* const* shift, float* const* bias_folded, const int* fold,
-                                const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
+                                const int* wino, const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
                                 int perm_rows, int perm_C, int perm_Fp, void* stream);
 
 // internal (conv.hip): sed_conv3x3_wgrad_ex whose exact-fp32 MFMA kernels add 1 to *arrive (agent scope) as each workgroup

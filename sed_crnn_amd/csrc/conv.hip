@@ -171,7 +171,9 @@ __global__ void conv_pack_w_multi_k(ConvPackMulti a, int n) {
         return;
     }
     const int Cout = a.Cout[l], Cin = a.Cin[l];
-    if (a.wino_f[l] | a.wino_d[l]) wino_pack_one(a.w[l], a.wino_f[l] ? a.wf[l] : nullptr, a.wino_d[l] ? a.wd[l] : nullptr, Cout, Cin, i);
+    if (a.wino_f[l] | a.wino_d[l])
+        wino_pack_one(a.w[l], a.wino_f[l] ? a.wf[l] : nullptr, a.wino_d[l] ? a.wd[l] : nullptr, Cout, Cin, i,
+                      a.fold[l] ? a.gamma[l] : nullptr, a.rv[l], a.eps);
     if (a.gamma[l] && i < Cout) {
         const float sc = a.gamma[l][i] / sqrtf(a.rv[l][i] + a.eps), sh = a.beta[l][i] - a.rm[l][i] * sc;      // = bn_finalize_eval_k
         if (a.scale_out[l]) { a.scale_out[l][i] = sc; a.shift_out[l][i] = sh; }
@@ -223,7 +225,7 @@ int sed_internal_conv_pack_multi(int n, const float* const* w, float* const* wf,
 int sed_internal_conv_pack_eval(int n, const float* const* w, const float* const* bias, const float* const* gamma,
                                 const float* const* beta, const float* const* rm, const float* const* rv, float eps,
                                 float* const* wf, float* const* scale, float* const* shift, float* const* bias_folded, const int* fold,
-                                const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
+                                const int* wino, const int* Cout, const int* Cin, const float* perm_src0, const float* perm_src1, float* perm_dst,
                                 int perm_rows, int perm_C, int perm_Fp, void* stream) {
     SED_REQUIRE(n > 0 && n <= SED_MAX_CONV && w && gamma && beta && rm && rv && wf && scale && shift && fold && Cout && Cin, "conv_pack_eval: bad arguments");
     ConvPackMulti a{};
@@ -233,6 +235,8 @@ int sed_internal_conv_pack_eval(int n, const float* const* w, const float* const
         a.w[l] = w[l]; a.wf[l] = wf[l]; a.Cout[l] = Cout[l]; a.Cin[l] = Cin[l];
         a.gamma[l] = gamma[l]; a.beta[l] = beta[l]; a.rm[l] = rm[l]; a.rv[l] = rv[l]; a.bias[l] = bias ? bias[l] : nullptr;
         a.scale_out[l] = scale[l]; a.shift_out[l] = shift[l]; a.bias_out[l] = bias_folded ? bias_folded[l] : nullptr; a.fold[l] = fold[l];
+        a.wino_f[l] = (wino && wino[l]) ? 1 : 0;
+        SED_REQUIRE(!a.wino_f[l] || (Cout[l] % 64 == 0 && Cin[l] % 64 == 0), "conv_pack_eval: layer %d cannot take the Winograd packing", l);
     }
     a.eps = eps;
     if (perm_src0) {

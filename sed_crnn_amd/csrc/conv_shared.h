@@ -30,7 +30,9 @@ __host__ __device__ inline size_t wino_frag_index(int comp, int k, int n, int K,
 #define WN_ZTAIL 256        // zero floats behind the packed weights: the source of the patch's zero padding (LDS-DMA cannot write a constant)
 // one thread per (co, ci): U = G g G^T for the forward (g[a][c] = w[co][ci][kh = c][kw = a]: a runs along time, c along mel) and for
 // the data gradient (contraction over co, g'[a][c] = w[co][ci][2 - c][2 - a])
-__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin, int i) {
+// gamma / rv (may be NULL): the weights of output channel co are scaled by gamma[co] / sqrt(rv[co] + eps) first (inference: BatchNorm folded)
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin, int i,
+                                              const float* __restrict__ gamma = nullptr, const float* __restrict__ rv = nullptr, float eps = 0.f) {
     if (i < WN_ZTAIL) {
         if (uf) uf[(size_t)16 * Cout * Cin + i] = 0.f;
         if (ud) ud[(size_t)16 * Cout * Cin + i] = 0.f;
@@ -42,6 +44,11 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) g[kw][kh] = w[(size_t)i * 9 + kh * 3 + kw];
+    if (gamma) {
+        const float sc = gamma[co] / sqrtf(rv[co] + eps);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k / 3][k % 3] *= sc;
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         float* dst = pass ? ud : uf;

@@ -93,8 +93,8 @@ int build_layout(const sed_net_cfg* c, int training, Layout* L) {
         // inference: blocks >= 1 on the 128-wide exact-fp32 MFMA tile with the reference's (1,2) pool (sed.py:90) end in the pooling
         // epilogue; everything else (and every training plan) keeps the conv output + the BatchNorm/ReLU/pool pass
         q.ev = (!training && l > 0 && c->conv_mode == 0 && q.pf == 1 && q.pt == 2 &&
-                sed_conv3x3_bn_relu_pool_eval_supported(c->B, q.Cin, q.F, q.T, q.C)) ? 1 : 0;
-        if (q.ev) q.wino = 0;
+                (q.wino || sed_conv3x3_bn_relu_pool_eval_supported(c->B, q.Cin, q.F, q.T, q.C))) ? 1 : 0;
+        // (.wino of a pooling-epilogue block: the Winograd kernel with that epilogue; .wino_d is a training-only notion)
         size_t nout = (q.fused || q.ev) ? 64 : (size_t)c->B * q.T * q.F * q.C, npool = (size_t)c->B * q.Tp * q.Fp * q.C;
         L->wp_f[l] = cv.take(q.wino ? sed_conv3x3_wino_packed_floats(q.C, q.Cin) : (size_t)9 * q.C * q.Cin);
         L->wp_d[l] = cv.take(q.wino_d ? sed_conv3x3_wino_packed_floats(q.C, q.Cin) : (size_t)9 * q.C * q.Cin);
@@ -263,16 +263,16 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
         const float* w[SED_MAX_CONV]; const float* bs[SED_MAX_CONV]; const float* gm[SED_MAX_CONV]; const float* bt[SED_MAX_CONV];
         const float* rm[SED_MAX_CONV]; const float* rv[SED_MAX_CONV];
         float* wf[SED_MAX_CONV]; float* sc[SED_MAX_CONV]; float* sh[SED_MAX_CONV]; float* bf[SED_MAX_CONV];
-        int fold[SED_MAX_CONV], co[SED_MAX_CONV], ci[SED_MAX_CONV];
+        int fold[SED_MAX_CONV], co[SED_MAX_CONV], ci[SED_MAX_CONV], wn[SED_MAX_CONV];
         for (int l = 0; l < L.n_conv; ++l) {
             SED_REQUIRE(p->conv_w[l] && p->conv_b[l] && p->bn_g[l] && p->bn_b[l] && p->bn_rm[l] && p->bn_rv[l],
                         "net_forward: missing parameters of conv block %d", l);
             w[l] = p->conv_w[l]; bs[l] = p->conv_b[l]; gm[l] = p->bn_g[l]; bt[l] = p->bn_b[l]; rm[l] = p->bn_rm[l]; rv[l] = p->bn_rv[l];
             wf[l] = ws + L.wp_f[l]; sc[l] = ws + L.scale[l]; sh[l] = ws + L.shift[l]; bf[l] = ws + L.bias_f[l];
-            fold[l] = L.cv[l].ev; co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin;
+            fold[l] = L.cv[l].ev; co[l] = L.cv[l].C; ci[l] = L.cv[l].Cin; wn[l] = L.cv[l].ev && L.cv[l].wino;
         }
         if (wih_permuted) SED_REQUIRE(p->gru_wih[0][0] && p->gru_wih[0][1], "net_forward: missing parameters of GRU layer 0");
-        SED_TRY(sed_internal_conv_pack_eval(L.n_conv, w, bs, gm, bt, rm, rv, c->bn_eps, wf, sc, sh, bf, fold, co, ci,
+        SED_TRY(sed_internal_conv_pack_eval(L.n_conv, w, bs, gm, bt, rm, rv, c->bn_eps, wf, sc, sh, bf, fold, wn, co, ci,
                                             wih_permuted ? p->gru_wih[0][0] : nullptr, wih_permuted ? p->gru_wih[0][1] : nullptr,
                                             ws + L.wih_perm, 3 * L.gr[0].H, qtop.C, qtop.Fp, stream));
         for (int l = 0; l < L.n_conv; ++l) {
@@ -282,6 +282,8 @@ static int forward_impl(const sed_net_cfg* c, const sed_net_params* p, const flo
             if (q.fused) {
                 SED_TRY(sed_conv1_bn_relu_pool_drop_fwd(in, ws + L.wp_f[l], p->conv_b[l], ws + L.scale[l], ws + L.shift[l], ws + L.pooled[l],
                                                         B, q.Cin, q.F, q.T, q.C, q.pf, q.pt, 0.f, 0, nullptr, nullptr, stream));
+            } else if (q.ev && q.wino) {
+                SED_TRY(sed_conv3x3_wino_bn_relu_pool_eval(in, ws + L.wp_f[l], ws + L.bias_f[l], ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, stream));
             } else if (q.ev) {          // (the last block's output stays channels-last: the GRU projection reads re-ordered weights)
                 SED_TRY(sed_conv3x3_bn_relu_pool_eval(in, ws + L.wp_f[l], ws + L.bias_f[l], ws + L.pooled[l], B, q.Cin, q.F, q.T, q.C, stream));
             } else {

@@ -46,15 +46,31 @@ struct WinoGeo {
 };
 
 // ───────────────────────── weight transform + packing ─────────────────────────
-__global__ void conv_pack_wino_k(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin) {
-    wino_pack_one(w, uf, ud, Cout, Cin, blockIdx.x * blockDim.x + threadIdx.x);
+__global__ void conv_pack_wino_k(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin,
+                                 const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* __restrict__ bias_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gamma && i < Cout) {                         // inference: BatchNorm on running statistics folded into weights and bias
+        const float sc = gamma[i] / sqrtf(rv[i] + eps);
+        bias_out[i] = (bias ? bias[i] : 0.f) * sc + (beta[i] - rm[i] * sc);
+    }
+    wino_pack_one(w, uf, ud, Cout, Cin, i, gamma, rv, eps);
 }
 
 extern "C" size_t sed_conv3x3_wino_packed_floats(int Cout, int Cin) { return (size_t)16 * Cout * Cin + WN_ZTAIL; }
 extern "C" int sed_conv3x3_wino_pack_weights(const float* w, float* uf, float* ud, int Cout, int Cin, void* stream) {
     SED_REQUIRE(w && (uf || ud) && Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0, "conv3x3_wino_pack_weights: bad arguments (channel counts: multiples of 64)");
-    conv_pack_wino_k<<<cdiv(Cout * Cin, 256), 256, 0, as_stream(stream)>>>(w, uf, ud, Cout, Cin);
+    conv_pack_wino_k<<<cdiv(Cout * Cin, 256), 256, 0, as_stream(stream)>>>(w, uf, ud, Cout, Cin, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr);
     SED_LAUNCH_CHECK("conv_pack_wino");
+    return 0;
+}
+extern "C" int sed_conv3x3_wino_pack_weights_bn_folded(const float* w, const float* bias, const float* gamma, const float* beta,
+                                                       const float* running_mean, const float* running_var, float eps,
+                                                       float* uf, float* bias_folded, int Cout, int Cin, void* stream) {
+    SED_REQUIRE(w && gamma && beta && running_mean && running_var && uf && bias_folded && Cout > 0 && Cin > 0 && Cout % 64 == 0 && Cin % 64 == 0,
+                "conv3x3_wino_pack_weights_bn_folded: bad arguments (channel counts: multiples of 64)");
+    conv_pack_wino_k<<<cdiv(Cout * Cin, 256), 256, 0, as_stream(stream)>>>(w, uf, nullptr, Cout, Cin, bias, gamma, beta, running_mean, running_var, eps, bias_folded);
+    SED_LAUNCH_CHECK("conv_pack_wino (folded)");
     return 0;
 }
 
@@ -93,7 +109,10 @@ int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
 // RGC > 0 (data gradient of the block above the recomputed first block with RGC input channels, pool (1,2)): the epilogue also forms
 // that block's weight-gradient sums R_k from the gradient values in registers, exactly as the direct kernel's RG epilogue does
 // (conv.hip): the network input under the block's tile rows is held in LDS, the arg-max bits pick the time row.
-template <int NH, bool BNR, int RGC = 0>
+// EV (inference, sed.py:128-141 with optim=None): BatchNorm is folded into the transformed weights and the bias by the packing
+// launch, and the epilogue applies ReLU + the (1,2) time pool before anything is written — the two time rows of a 2x2 tile ARE a
+// pooling pair: `y` is the pooled output [B][T/2][F][Cout], the un-pooled tensor never exists.
+template <int NH, bool BNR, int RGC = 0, bool EV = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     const float* __restrict__ x, const float* __restrict__ uq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, WinoGeo geo, ConvBnRed br) {
@@ -101,6 +120,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     constexpr int HBUF = NH * 1024;                       // floats per patch buffer (NH KiB per wave)
     constexpr bool RG = RGC > 0;
     static_assert(!RG || BNR, "the tap sums belong to the BatchNorm-backward epilogue");
+    static_assert(!EV || !BNR, "the pooling epilogue belongs to the inference forward");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     if (tid < 64) {
         const int q = q0 + tid;
         const int ty = sed_fdiv(q < ntile ? q : 0, geo.invFw), tf = q - ty * Fw;
-        rowtab[tid] = q < ntile ? (unsigned)(((2 * ty) * F + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
+        rowtab[tid] = q < ntile ? (unsigned)(((EV ? ty : 2 * ty) * F + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
         if (RG) xofftab[tid] = (unsigned)(2 * tf * XT + 4 * (ty - ty0));
     }
     if (RG) {
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     const int cb = co0 + nt * 32 + c4;
     f32x4 bv = {0, 0, 0, 0};
     if (bias) bv = *(const f32x4*)(bias + cb);
-    char* const yb = (char*)(y + (size_t)b * T * F * Cout + cb);
+    char* const yb = (char*)(y + (size_t)b * (EV ? T >> 1 : T) * F * Cout + cb);
     const char* const qb = BNR ? (const char*)(br.pooled + (size_t)b * T * F * Cout + cb) : nullptr;
     f32x4 q_kr = {0, 0, 0, 0}, q_nb = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     if (BNR) {
@@ -351,6 +371,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi) z[xi] = *(const f32x4*)(smem + ((((xi * 2 + jj) * 2 + mt) * 2 + nt) << 10) + m * 32 + c4);
             const f32x4 o[2] = {z[0] + z[1] + z[2] + bv, z[1] - z[2] - z[3] + bv};
+            if (EV) {
+                f32x4 pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pl[e] = fmaxf(fmaxf(o[0][e], o[1][e]), 0.f);
+                *(f32x4*)(yb + ro + jj * cstride) = pl;
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const unsigned off = ro + i * rstride + jj * cstride;
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             }
         }
     }
-    if (stat) {
+    if (stat && !EV) {
         // a1 / a2: forward (sum y, sum y^2), data gradient (sum g, sum g*xhat) of this lane's four channels over its rows
         float* red = smem + 32768;                    // [4 waves][2][32] behind the exchange tiles
         if (BNR) { a1 *= br.inv_keep; a2 *= br.inv_keep; }
@@ -452,26 +479,27 @@ static unsigned long long* g_wino_dbg = nullptr;
 extern "C" int sed_conv3x3_wino_phase_ticks(unsigned long long* buf) { g_wino_dbg = buf; return 0; }
 
 int sed_internal_wino_launch(const float* x, const float* uq, const float* bias, float* y, float* stat, const ConvBnRed* br,
-                             int rgc, int B, int Cin, int F, int T, int Cout, hipStream_t s) {
+                             int rgc, int B, int Cin, int F, int T, int Cout, hipStream_t s) {      // rgc == -1: the pooling inference epilogue
     WinoGeo g;
     SED_REQUIRE(wino_geo(B, Cin, F, T, Cout, &g), "conv3x3_wino: shape B=%d Cin=%d F=%d T=%d Cout=%d is not supported (sed_conv3x3_wino_rows)", B, Cin, F, T, Cout);
-    SED_REQUIRE(rgc >= 0 && rgc <= 2 && (rgc == 0 || (br && br->x1 && br->bits && br->rgp)), "conv3x3_wino: bad tap-sum arguments");
+    SED_REQUIRE(rgc >= -1 && rgc <= 2 && (rgc <= 0 || (br && br->x1 && br->bits && br->rgp)) && (rgc >= 0 || (!br && !stat)), "conv3x3_wino: bad epilogue arguments");
     g.dbg = g_wino_dbg;
-    if (rgc) {       // + the window-offset table, the input patch and the tap-sum exchange of the four waves
+    if (rgc > 0) {       // + the window-offset table, the input patch and the tap-sum exchange of the four waves
         g.lds += ((size_t)64 + (size_t)rgc * (F + 2) * (4 * g.TR + 2) + (size_t)4 * 9 * rgc * 32) * sizeof(float);
         SED_REQUIRE(g.lds <= 160 * 1024, "conv3x3_wino: the first block's input patch does not fit the LDS (F=%d)", F);
     }
     const dim3 grid(g.nblk * g.ncoh, B);
     const ConvBnRed none{};
-#define WN_LAUNCH(NHv, BNRv, RGv)                                                                                          \
-    do {                                                                                                                      \
-        SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv, RGv>), g.lds));                                                       \
-        conv3x3_wino_k<NHv, BNRv, RGv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);     \
+#define WN_LAUNCH(NHv, BNRv, RGv, EVv)                                                                                          \
+    do {                                                                                                                           \
+        SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv, RGv, EVv>), g.lds));                                                       \
+        conv3x3_wino_k<NHv, BNRv, RGv, EVv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);     \
     } while (0)
-    if (rgc == 1) WN_LAUNCH(WN_NHMAX, true, 1);
-    else if (rgc == 2) WN_LAUNCH(WN_NHMAX, true, 2);
-    else if (br) WN_LAUNCH(WN_NHMAX, true, 0);
-    else WN_LAUNCH(WN_NHMAX, false, 0);
+    if (rgc == 1) WN_LAUNCH(WN_NHMAX, true, 1, false);
+    else if (rgc == 2) WN_LAUNCH(WN_NHMAX, true, 2, false);
+    else if (rgc == -1) WN_LAUNCH(WN_NHMAX, false, 0, true);
+    else if (br) WN_LAUNCH(WN_NHMAX, true, 0, false);
+    else WN_LAUNCH(WN_NHMAX, false, 0, false);
 #undef WN_LAUNCH
     SED_LAUNCH_CHECK("conv3x3_wino");
     return 0;
@@ -519,4 +547,13 @@ extern "C" int sed_conv3x3_wino_dgrad_bnred_rg(const float* dy, const float* ud,
     const ConvBnRed br{pooled, gamma, beta, nullptr, mean, rstd, 1.f - drop_p, 1.f / (1.f - drop_p), 1, 2, F, 2 * T,
                        x1, argmax_bits, rg_partials, 0.f};
     return sed_internal_wino_launch(dy, ud, nullptr, dx, partials, &br, Cin1, B, C, F, T, Cin, s);
+}
+
+// inference: conv + BatchNorm (running statistics, folded by sed_conv3x3_wino_pack_weights_bn_folded) + ReLU + (1,2) time pool
+extern "C" int sed_conv3x3_wino_bn_relu_pool_eval(const float* x, const float* uf_folded, const float* bias_folded, float* pooled,
+                                                  int B, int Cin, int F, int T, int Cout, void* stream) {
+    SED_REQUIRE(x && uf_folded && bias_folded && pooled, "conv3x3_wino_bn_relu_pool_eval: null pointer");
+    hipStream_t s = as_stream(stream);
+    SedProfScope prof(SED_K_CONV_MFMA_FWD, s, 2.0 * 9.0 * Cin * Cout * (double)B * T * F);
+    return sed_internal_wino_launch(x, uf_folded, bias_folded, pooled, nullptr, nullptr, -1, B, Cin, F, T, Cout, s);
 }

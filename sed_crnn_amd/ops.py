@@ -63,11 +63,23 @@ def conv3x3_wino_fwd(x, up, bias, Cout, want_stats=True):
     return y, stat
 
 
-def conv3x3_bn_relu_pool_eval(x, w, bias, gamma, beta, running_mean, running_var, eps=1e-5):
+def conv3x3_bn_relu_pool_eval(x, w, bias, gamma, beta, running_mean, running_var, eps=1e-5, wino=False):
     """inference: x [B,T,F,Cin] channels-last -> relu(max_pool((1,2))(bn_eval(conv3x3(x)))) [B,T//2,F,Cout] in one launch
-    (BatchNorm folded into the packed weights; sed_conv3x3_pack_weights_bn_folded + sed_conv3x3_bn_relu_pool_eval)"""
+    (BatchNorm folded into the packed weights; sed_conv3x3_pack_weights_bn_folded + sed_conv3x3_bn_relu_pool_eval; wino: the
+    Winograd forms of both)"""
     B, T, F, Cin = x.shape
     Cout = w.shape[0]
+    if wino:
+        if lib().sed_conv3x3_wino_rows(B, Cin, F, T, Cout) <= 0:
+            raise ValueError("conv3x3_bn_relu_pool_eval: shape not supported by the Winograd kernel")
+        uf = torch.empty(lib().sed_conv3x3_wino_packed_floats(Cout, Cin), device=x.device)
+        bf = torch.empty(Cout, device=x.device)
+        check(lib().sed_conv3x3_wino_pack_weights_bn_folded(ptr(_f32c(w)), ptr(bias), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                            eps, ptr(uf), ptr(bf), Cout, Cin, stream_ptr()), "conv3x3_wino_pack_weights_bn_folded")
+        out = torch.empty(B, T // 2, F, Cout, device=x.device)
+        check(lib().sed_conv3x3_wino_bn_relu_pool_eval(ptr(_f32c(x)), ptr(uf), ptr(bf), ptr(out), B, Cin, F, T, Cout, stream_ptr()),
+              "conv3x3_wino_bn_relu_pool_eval")
+        return out
     if not lib().sed_conv3x3_bn_relu_pool_eval_supported(B, Cin, F, T, Cout):
         raise ValueError("conv3x3_bn_relu_pool_eval: shape not supported")
     wf = torch.empty(9, Cout, Cin, device=x.device)

@@ -625,6 +625,10 @@ def test_inference_conv_with_folded_batchnorm_relu_and_pool_in_the_epilogue(ops,
     close(out.permute(0, 3, 2, 1), ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-5)
     out2 = ops.conv3x3_bn_relu_pool_eval(g(x.permute(0, 3, 2, 1)), g(w), g(bias), g(gamma), g(beta), g(rm), g(rv))
     assert torch.equal(out, out2)
+    # the Winograd kernel with the same epilogue (the eval plan's default where the shape takes it: 128 input channels, even T and F)
+    if lib().sed_conv3x3_wino_rows(B, Cin, Fm, T, Cout) > 0:
+        outw = ops.conv3x3_bn_relu_pool_eval(g(x.permute(0, 3, 2, 1)), g(w), g(bias), g(gamma), g(beta), g(rm), g(rv), wino=True)
+        close(outw.permute(0, 3, 2, 1), ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-5)
 
 
 GEMM_CASES = [(64, 64, 64), (130, 70, 50), (4096, 96, 320), (256, 384, 5120), (384, 640, 512), (33, 17, 9), (512, 768, 1024)]
