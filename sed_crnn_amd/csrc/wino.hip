@@ -39,7 +39,8 @@ typedef __attribute__((address_space(1))) const void* sed_gptr_t;
 typedef __attribute__((address_space(3))) void* sed_lptr_t;
 
 struct WinoGeo {
-    int Fw, Tw, ntile, nblk, TR, F2, H2, HR, nb8, ncoh, NH;
+    int Fw;        // tiles per row of a COLUMN GROUP (the mel axis is cut into ncg groups of Fw tiles when a whole row's patch is too large)
+    int ncg, Tw, ntile, nblk, TR, F2, H2, HR, nb8, ncoh, NH;      // ntile / nblk: per sequence and column group
     float invFw, invF2;
     size_t lds;
     unsigned long long* dbg;      // measurement only (sed_conv3x3_wino_phase_ticks): per-phase s_memrealtime sums, NULL in production
@@ -78,16 +79,25 @@ extern "C" int sed_conv3x3_wino_pack_weights_bn_folded(const float* w, const flo
 static bool wino_geo(int B, int Cin, int F, int T, int Cout, WinoGeo* g) {
     if (B <= 0 || Cin != WN_CIN || Cout <= 0 || Cout % 64 != 0 || F < 2 || T < 2 || (F & 1) || (T & 1)) return false;
     if ((size_t)B * T * F * Cin >= ((size_t)1 << 32) || (size_t)T * F * Cout >= ((size_t)1 << 30)) return false;
-    g->Fw = F / 2; g->Tw = T / 2; g->ntile = g->Fw * g->Tw; g->nblk = cdiv(g->ntile, 64);
-    int TR = 0;
-    for (int blk = 0; blk < g->nblk; ++blk) {
-        const int q1 = blk * 64 + 63 < g->ntile ? blk * 64 + 63 : g->ntile - 1;
-        const int n = q1 / g->Fw - (blk * 64) / g->Fw + 1;
-        if (n > TR) TR = n;
+    g->Tw = T / 2;
+    // 64 consecutive tiles of a column group: its tile rows' patch (2 TR + 2 time rows x 2 Fw + 2 mel columns) has to fit WN_NHMAX KiB
+    // per wave and 32-channel slice.  Whole rows first (no column halo between workgroups); 128 mel bins: two groups of 32 tiles
+    // (two tile rows per block: 6 x 66 positions instead of 4 x 130)
+    bool ok = false;
+    for (int ncg = 1; ncg <= 8 && !ok; ncg *= 2) {
+        if ((F / 2) % ncg) break;
+        g->ncg = ncg; g->Fw = F / 2 / ncg; g->ntile = g->Fw * g->Tw; g->nblk = cdiv(g->ntile, 64);
+        int TR = 0;
+        for (int blk = 0; blk < g->nblk; ++blk) {
+            const int q1 = blk * 64 + 63 < g->ntile ? blk * 64 + 63 : g->ntile - 1;
+            const int n = q1 / g->Fw - (blk * 64) / g->Fw + 1;
+            if (n > TR) TR = n;
+        }
+        g->TR = TR; g->F2 = 2 * g->Fw + 2; g->H2 = g->F2 / 2; g->HR = (2 * TR + 2) * g->F2; g->nb8 = cdiv(g->HR, 8);
+        g->NH = cdiv(g->nb8, 4);
+        ok = g->NH <= WN_NHMAX;
     }
-    g->TR = TR; g->F2 = F + 2; g->H2 = g->F2 / 2; g->HR = (2 * TR + 2) * g->F2; g->nb8 = cdiv(g->HR, 8);
-    g->NH = cdiv(g->nb8, 4);
-    if (g->NH > WN_NHMAX) return false;
+    if (!ok) return false;
     g->NH = WN_NHMAX;
     g->ncoh = Cout / 64;
     g->invFw = 1.0f / (float)g->Fw; g->invF2 = 1.0f / (float)g->F2;
@@ -102,7 +112,7 @@ static bool wino_geo(int B, int Cin, int F, int T, int Cout, WinoGeo* g) {
 
 int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
     WinoGeo g;
-    return wino_geo(B, Cin, F, T, Cout, &g) ? B * g.nblk : 0;
+    return wino_geo(B, Cin, F, T, Cout, &g) ? B * g.nblk * g.ncg : 0;
 }
 
 // ───────────────────────── the kernel ─────────────────────────
@@ -129,19 +139,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 
     // workgroup -> (sequence, tile block, channel half).  Workgroups are dealt round-robin to the 8 XCDs in launch order: the
     // channel halves of a block and the blocks of a sequence are given to the same XCD (they share the input patch through its L2)
-    int blk, coh, b;
+    int blka, coh, b;                                  // blka = block x column group of the sequence
     {
-        const int bx = blockIdx.x, by = blockIdx.y;
+        const int bx = blockIdx.x, by = blockIdx.y, nba = geo.nblk * geo.ncg;
         if ((gridDim.y & 7) == 0) {
             const int id = by * (int)gridDim.x + bx, xcd = id & 7, j = id >> 3;
             coh = j % geo.ncoh;
             const int jj = j / geo.ncoh;
-            b = xcd + 8 * (jj / geo.nblk);
-            blk = jj % geo.nblk;
+            b = xcd + 8 * (jj / nba);
+            blka = jj % nba;
         } else {
-            coh = bx % geo.ncoh; blk = bx / geo.ncoh; b = by;
+            coh = bx % geo.ncoh; blka = bx / geo.ncoh; b = by;
         }
     }
+    const int blk = blka / geo.ncg, cgp = blka - blk * geo.ncg;      // neighbouring column groups are neighbours in launch order
+    const int fg0 = 2 * cgp * geo.Fw;                                   // first mel column of the group
     const int Fw = geo.Fw, F2 = geo.F2, H2 = geo.H2, ntile = geo.ntile;
     const int q0 = blk * 64, ty0 = q0 / Fw;
     const int co0 = coh * 64;
@@ -179,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             const int P = (u * 4 + wave) * 8 + pp;
             const int tt = sed_fdiv(P, geo.invF2), cx = P - tt * F2;
             const int ff = cx < H2 ? 2 * cx : 2 * (cx - H2) + 1;
-            const int t = 2 * ty0 - 1 + tt, f = ff - 1;
+            const int t = 2 * ty0 - 1 + tt, f = fg0 + ff - 1;
             const bool in = P < geo.HR && t >= 0 && t < T && f >= 0 && f < F;
             hp[u] = in ? x + ((((size_t)b * T + t) * F + f) * CIN + Q * 4) : zrow + Q * 4;
         }
@@ -200,17 +212,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     if (tid < 64) {
         const int q = q0 + tid;
         const int ty = sed_fdiv(q < ntile ? q : 0, geo.invFw), tf = q - ty * Fw;
-        rowtab[tid] = q < ntile ? (unsigned)(((EV ? ty : 2 * ty) * F + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
-        if (RG) xofftab[tid] = (unsigned)(2 * tf * XT + 4 * (ty - ty0));
+        rowtab[tid] = q < ntile ? (unsigned)(((EV ? ty : 2 * ty) * F + fg0 + 2 * tf) * Cout) * 4u : 0xFFFFFFFFu;
+        if (RG) xofftab[tid] = (unsigned)((fg0 + 2 * tf) * XT + 4 * (ty - ty0));
     }
     if (RG) {
-        for (int i = tid; i < F2 * XT; i += 256) {
+        for (int i = tid; i < (F + 2) * XT; i += 256) {
             const int ff = i / XT, tt = i - ff * XT;
-            const int f = ff - 1, t = 4 * ty0 - 1 + tt;
+            const int f = ff - 1, t = 4 * ty0 - 1 + tt;          // (all F + 2 mel columns: indexed by the absolute column)
             const bool in = f >= 0 && f < F && t >= 0 && t < br.Ty;
 #pragma unroll
             for (int ci = 0; ci < RGC; ++ci)
-                xs[ci * F2 * XT + i] = in ? br.x1[(((size_t)b * RGC + ci) * F + f) * br.Ty + t] : 0.f;
+                xs[ci * (F + 2) * XT + i] = in ? br.x1[(((size_t)b * RGC + ci) * F + f) * br.Ty + t] : 0.f;
         }
     }
 
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
                         const f32x4 gA = g0 - g1;
 #pragma unroll
                         for (int ci = 0; ci < RGC; ++ci) {
-                            const float* xb = xs + ci * F2 * XT + xo + jj * XT + 2 * i;
+                            const float* xb = xs + ci * (F + 2) * XT + xo + jj * XT + 2 * i;
 #pragma unroll
                             for (int kh = 0; kh < 3; ++kh) {
                                 const f32x2 x01 = *(const f32x2*)(xb + kh * XT), x23 = *(const f32x2*)(xb + kh * XT + 2);
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             *(f32x4*)(red + (wave * 2 + 0) * 32 + c4) = a1;
             *(f32x4*)(red + (wave * 2 + 1) * 32 + c4) = a2;
         }
-        float* red2 = xs + RGC * F2 * XT;              // [4 waves][9 RGC][32]: this wave's 32 channels of the R_k (behind xs, which others may still read)
+        float* red2 = xs + RGC * (F + 2) * XT;              // [4 waves][9 RGC][32]: this wave's 32 channels of the R_k (behind xs, which others may still read)
         if (RG) {
 #pragma unroll
             for (int k = 0; k < 9 * RGC; ++k) {
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             }
         }
         __syncthreads();
-        const size_t row = (size_t)b * geo.nblk + blk;
+        const size_t row = (size_t)b * geo.nblk * geo.ncg + blka;
         if (tid < 128) {
             const int which = tid >> 6, c = tid & 63, cn = c >> 5, cr = c & 31;
             const float a = red[((0 * 2 + cn) * 2 + which) * 32 + cr] + red[((1 * 2 + cn) * 2 + which) * 32 + cr];
@@ -488,7 +500,7 @@ int sed_internal_wino_launch(const float* x, const float* uq, const float* bias,
         g.lds += ((size_t)64 + (size_t)rgc * (F + 2) * (4 * g.TR + 2) + (size_t)4 * 9 * rgc * 32) * sizeof(float);
         SED_REQUIRE(g.lds <= 160 * 1024, "conv3x3_wino: the first block's input patch does not fit the LDS (F=%d)", F);
     }
-    const dim3 grid(g.nblk * g.ncoh, B);
+    const dim3 grid(g.nblk * g.ncg * g.ncoh, B);
     const ConvBnRed none{};
 #define WN_LAUNCH(NHv, BNRv, RGv, EVv)                                                                                          \
     do {                                                                                                                           \
@@ -534,7 +546,7 @@ extern "C" int sed_conv3x3_wino_rg_rows(int B, int C, int F, int T, int Cin, int
     WinoGeo g;
     if (Cin1 < 1 || Cin1 > 2 || !wino_geo(B, C, F, T, Cin, &g)) return 0;
     const size_t lds = g.lds + ((size_t)64 + (size_t)Cin1 * (F + 2) * (4 * g.TR + 2) + (size_t)4 * 9 * Cin1 * 32) * sizeof(float);
-    return lds <= 160 * 1024 ? B * g.nblk : 0;
+    return lds <= 160 * 1024 ? B * g.nblk * g.ncg : 0;
 }
 extern "C" int sed_conv3x3_wino_dgrad_bnred_rg(const float* dy, const float* ud, float* dx, float* partials, const float* pooled,
                                                const float* gamma, const float* beta, const float* mean, const float* rstd, float drop_p,

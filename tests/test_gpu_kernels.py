@@ -280,12 +280,14 @@ def test_dgrad_with_fused_bn_backward_reduction_matches_the_two_pass_form(ops, B
 
 
 @pytest.mark.parametrize("B,Fm,T,Cout", [(2, 40, 16, 128), (1, 40, 128, 128), (3, 40, 6, 128), (2, 20, 10, 64), (1, 10, 64, 128),
-                                          (2, 8, 2, 256), (1, 2, 2, 128), (9, 32, 12, 128), (8, 40, 64, 128)])
+                                          (2, 8, 2, 256), (1, 2, 2, 128), (9, 32, 12, 128), (8, 40, 64, 128),
+                                          (2, 128, 8, 128), (8, 128, 6, 128), (1, 64, 10, 128), (1, 256, 4, 128)])
 def test_conv3x3_winograd_forward_and_data_gradient(ops, B, Fm, T, Cout):
     """The Winograd F(2x2,3x3) form of the 128-channel convolutions (wino.hip) against torch in float64, next to the direct
     exact-fp32 kernel on the same inputs: forward with bias and the statistic partial rows, and the data gradient (same kernel,
     flipped / transposed transformed weights).  Mel widths whose tile rows do not divide the 64-tile blocks (40, 20, 10), blocks
-    that end in the middle of a sequence's last tile row, a single tile, batch sizes with and without the XCD-aware order.  The
+    that end in the middle of a sequence's last tile row, a single tile, batch sizes with and without the XCD-aware order, and
+    the wide mel axes (128 bins of config 5, 256) whose tile rows are cut into column groups with a halo between workgroups.  The
     transforms only add and halve, so the error stays within a small multiple of the direct kernel's (asserted: 4x + an ulp term)."""
     torch.manual_seed(B * 7 + Fm + T)
     Cin = 128
