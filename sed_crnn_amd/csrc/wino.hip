@@ -122,7 +122,9 @@ int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
 // EV (inference, sed.py:128-141 with optim=None): BatchNorm is folded into the transformed weights and the bias by the packing
 // launch, and the epilogue applies ReLU + the (1,2) time pool before anything is written — the two time rows of a 2x2 tile ARE a
 // pooling pair: `y` is the pooled output [B][T/2][F][Cout], the un-pooled tensor never exists.
-template <int NH, bool BNR, int RGC = 0, bool EV = false>
+// ABL (measurement builds only, -DWN_ABLATION: wrong results on purpose): 1 = no transform arithmetic, 2 = no weight-fragment loads
+// in the loop, 4 = no operand reads from LDS in the loop, 8 = no patch DMA in the loop
+template <int NH, bool BNR, int RGC = 0, bool EV = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     const float* __restrict__ x, const float* __restrict__ uq, const float* __restrict__ bias,
     float* __restrict__ y, float* __restrict__ stat, int B, int F, int T, int Cout, WinoGeo geo, ConvBnRed br) {
@@ -254,6 +256,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) u[c] = dA[c] + sg * dB[c];
+            if (ABL & 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[mt][c] = dA[c] * dB[c][0];      // (one multiply per element keeps both reads alive)
+                continue;
+            }
             v[mt][0] = u[0] - u[2];
             v[mt][1] = u[1] + u[2];
             v[mt][2] = u[2] - u[1];
@@ -272,8 +279,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         const int cc = st >> 2, g = st & 3, par = st & 1;
         const bool more = cc + 1 < NCHUNK;
         __builtin_amdgcn_sched_barrier(0);
-        if (g == 0 && more) issue(cc + 1, smem + ((cc + 1) & 1) * HBUF);      // that buffer was last read before the barrier of step (cc-1, 2)
-        if (st + 1 < NSTEP) read_a(smem + (((st + 1) >> 2) & 1) * HBUF, (st + 1) & 3, va[par ^ 1]);
+        if (g == 0 && more && !(ABL & 8)) issue(cc + 1, smem + ((cc + 1) & 1) * HBUF);      // that buffer was last read before the barrier of step (cc-1, 2)
+        if (st + 1 < NSTEP) {
+            if (ABL & 4) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) va[par ^ 1][a][c] = va[par][a][c];
+            } else read_a(smem + (((st + 1) >> 2) & 1) * HBUF, (st + 1) & 3, va[par ^ 1]);
+        }
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
 #pragma unroll
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
                         acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[par][mt][nu][j], bq[nu][nt][j], acc[nu][mt][nt], 0, 0, 0);
-            if (st + 1 < NSTEP) load_b(nu, st + 1);
+            if (st + 1 < NSTEP && !(ABL & 2)) load_b(nu, st + 1);
         }
         // one MFMA, then up to two of the other instructions (transform arithmetic, LDS reads, fragment loads, DMA): one wave per
         // SIMD issues in order, what sits between two MFMAs must fit the 64-cycle shadow of the one in front
@@ -486,6 +500,10 @@ static int wino_set_lds(K kernel, size_t bytes) {
 }
 
 static unsigned long long* g_wino_dbg = nullptr;
+#ifdef WN_ABLATION
+static int g_wino_abl = 0;
+extern "C" int sed_conv3x3_wino_ablate(int mask) { g_wino_abl = mask; return 0; }
+#endif
 // measurement only: buf = 4 device uint64 (prologue, main loop, epilogue ticks of the 100 MHz clock summed over workgroups, workgroup
 // count), accumulated by every Winograd forward / data-gradient launch until reset with NULL
 extern "C" int sed_conv3x3_wino_phase_ticks(unsigned long long* buf) { g_wino_dbg = buf; return 0; }
@@ -507,6 +525,19 @@ int sed_internal_wino_launch(const float* x, const float* uq, const float* bias,
         SED_TRY(wino_set_lds((conv3x3_wino_k<NHv, BNRv, RGv, EVv>), g.lds));                                                       \
         conv3x3_wino_k<NHv, BNRv, RGv, EVv><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, br ? *br : none);     \
     } while (0)
+#ifdef WN_ABLATION
+    if (g_wino_abl && rgc == 0 && !br) {
+        switch (g_wino_abl) {
+            case 1: { SED_TRY(wino_set_lds((conv3x3_wino_k<WN_NHMAX, false, 0, false, 1>), g.lds)); conv3x3_wino_k<WN_NHMAX, false, 0, false, 1><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, none); break; }
+            case 2: { SED_TRY(wino_set_lds((conv3x3_wino_k<WN_NHMAX, false, 0, false, 2>), g.lds)); conv3x3_wino_k<WN_NHMAX, false, 0, false, 2><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, none); break; }
+            case 4: { SED_TRY(wino_set_lds((conv3x3_wino_k<WN_NHMAX, false, 0, false, 5>), g.lds)); conv3x3_wino_k<WN_NHMAX, false, 0, false, 5><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, none); break; }
+            case 8: { SED_TRY(wino_set_lds((conv3x3_wino_k<WN_NHMAX, false, 0, false, 8>), g.lds)); conv3x3_wino_k<WN_NHMAX, false, 0, false, 8><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, none); break; }
+            default: { SED_TRY(wino_set_lds((conv3x3_wino_k<WN_NHMAX, false, 0, false, 15>), g.lds)); conv3x3_wino_k<WN_NHMAX, false, 0, false, 15><<<grid, 256, g.lds, s>>>(x, uq, bias, y, stat, B, F, T, Cout, g, none); break; }
+        }
+        SED_LAUNCH_CHECK("conv3x3_wino (ablation)");
+        return 0;
+    }
+#endif
     if (rgc == 1) WN_LAUNCH(WN_NHMAX, true, 1, false);
     else if (rgc == 2) WN_LAUNCH(WN_NHMAX, true, 2, false);
     else if (rgc == -1) WN_LAUNCH(WN_NHMAX, false, 0, true);
