@@ -1859,19 +1859,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
             o.b[nt][1] = *(const f32x4*)(dp + w_yb);
         }
     };
-    auto wmfma = [&](const WOps& o) {
+    // the transformed operands of one chunk: v[j][nu] (A, this wave's xi) and z[nt][j][nu] (B)
+    struct WT { float v[2][4]; float z[4][2][4]; };
+    auto wtransform = [&](const WOps& o, WT& t) {
         float u[6];
 #pragma unroll
         for (int c = 0; c < 4; ++c) u[c] = o.a[0][c] + w_sg * o.a[1][c];
         u[4] = o.a2[0][0] + w_sg * o.a2[1][0];
         u[5] = o.a2[0][1] + w_sg * o.a2[1][1];
-        float v[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            v[j][0] = u[2 * j] - u[2 * j + 2];
-            v[j][1] = u[2 * j + 1] + u[2 * j + 2];
-            v[j][2] = u[2 * j + 2] - u[2 * j + 1];
-            v[j][3] = u[2 * j + 1] - u[2 * j + 3];
+            t.v[j][0] = u[2 * j] - u[2 * j + 2];
+            t.v[j][1] = u[2 * j + 1] + u[2 * j + 2];
+            t.v[j][2] = u[2 * j + 2] - u[2 * j + 1];
+            t.v[j][3] = u[2 * j + 1] - u[2 * j + 3];
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -1880,12 +1881,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float c0 = yr[2 * j], c1 = yr[2 * j + 1];
-                const float z[4] = {c0, c0 + c1, c0 - c1, c1};
-#pragma unroll
-                for (int nu = 0; nu < 4; ++nu)
-                    acc[nu * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][nu], z[nu], acc[nu * 4 + nt], 0, 0, 0);
+                t.z[nt][j][0] = c0; t.z[nt][j][1] = c0 + c1; t.z[nt][j][2] = c0 - c1; t.z[nt][j][3] = c1;
             }
         }
+    };
+    auto wmfma = [&](const WT& t) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+                    acc[nu * 4 + nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(t.v[j][nu], t.z[nt][j][nu], acc[nu * 4 + nt], 0, 0, 0);
     };
 
     constexpr int BS = (NS + NB - 1) / NB;
@@ -1909,14 +1916,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
         const float* buf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;       // last read before the previous barrier
         if (WINO) {
-            WOps w0, w1;
-            wfetch(buf, 0, w0);
+            // operands are read one chunk ahead of their transform and transformed one chunk ahead of their MFMAs: a chunk's 32 MFMAs
+            // start with everything in registers (transforming at the head of the chunk left the MFMA pipe idle for ~40 vector
+            // instructions, five times per tile)
+            WOps w;
+            WT ta, tb;
+            wfetch(buf, 0, w);
+            wtransform(w, ta);
+            if (NCH > 1) wfetch(buf, 1, w);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                WOps& oc = (c & 1) ? w1 : w0;
-                WOps& on = (c & 1) ? w0 : w1;
+                WT& tc = (c & 1) ? tb : ta;
+                WT& tn = (c & 1) ? ta : tb;
                 __builtin_amdgcn_sched_barrier(0);
-                if (c + 1 < NCH) wfetch(buf, c + 1, on);
+                if (c + 1 < NCH) wtransform(w, tn);
+                if (c + 2 < NCH) wfetch(buf, c + 2, w);
                 if (c < NB) {
 #pragma unroll
                     for (int k = c * BS; k < (c + 1) * BS && k < NS; ++k) load_item(k);
@@ -1925,7 +1939,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_mfma_wgrad2_k(
 #pragma unroll
                     for (int k = (c - (NCH - NB)) * BS; k < (c - (NCH - NB) + 1) * BS && k < NS; ++k) commit_item(k, nbuf);
                 }
-                wmfma(oc);
+                wmfma(tc);
 #pragma unroll
                 for (int g = 0; g < 32; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA

@@ -763,6 +763,50 @@ def test_single_step_gradients_are_as_close_to_float64_as_torch_float32(sed):
     print(f"single-step gradient error vs float64: worst HIP/torch-f32 ratio over the parameters = {worst:.2f}")
 
 
+@pytest.mark.parametrize("direct", [False, True])
+def test_winograd_and_direct_conv_plans_both_match_golden_g5_and_the_oracle(sed, direct):
+    """The 128-channel blocks run as Winograd F(2x2,3x3) by default (forward, data gradient, weight gradient: wino.hip / the
+    Winograd form of conv3x3_mfma_wgrad2_k); `plan_flags = SED_NET_DIRECT_CONV` keeps the direct 36-product kernels.  Both plans
+    against the SAME references with the SAME tolerances: the full-width golden g5 (K = 1152: logits eval / train and every
+    gradient, sed.py:105-112,134-137) and a routed oracle comparison on a 2-channel C = 128 net; and the two plans' gradients
+    agree with each other far inside those tolerances."""
+    from oracle import crnn_ref
+    d = load_golden("g5_sed_c128.npz")
+    ref = crnn_ref.SedNetRef(conv_channels=128, dropout=0.0)
+    m = sed.TimePooledCRNN(conv_channels=128, dropout=0.0)
+    m.plan_flags = 0x4 if direct else 0
+    m.load_state_dict(crnn_ref.rs_state_dict(ref, seed=int(d["weight_seed"])))
+    m.cuda()
+    x, y = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["y"]).cuda()
+    m.eval()
+    _cmp(m(x), d["logits_eval"], atol=2e-4)
+    m.train()
+    out = m(x)
+    sed.BCEWithLogitsLoss()(out, y).backward()
+    _cmp(out, d["logits_train"], atol=2e-4)
+    named = dict(m.named_parameters())
+    for k in d:
+        if k.startswith("grad.") and k[5:] in named:
+            _cmp(named[k[5:]].grad, d[k], atol=5e-5, rtol=5e-3, msg=k)
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    # the other plan on the same weights and batch
+    m2 = sed.TimePooledCRNN(conv_channels=128, dropout=0.0)
+    m2.plan_flags = 0 if direct else 0x4
+    m2.load_state_dict(crnn_ref.rs_state_dict(ref, seed=int(d["weight_seed"])))
+    m2.cuda().train()
+    sed.BCEWithLogitsLoss()(m2(x), y).backward()
+    for k, p in m2.named_parameters():
+        num = float((p.grad - grads[k]).norm()), float(grads[k].norm())
+        # (conv biases in front of a BatchNorm have a zero gradient up to rounding: ~1e-8 of noise on both sides)
+        assert num[0] <= 2e-5 * num[1] + 1e-7, (k, num)
+    torch.manual_seed(7)
+    ref2 = crnn_ref.SedNetRef(conv_channels=128, dropout=0.0, in_channels=2, n_mels=40, gru_hidden=128)
+    m3 = sed.TimePooledCRNN(conv_channels=128, dropout=0.0, in_channels=2, n_mels=40, gru_hidden=128)
+    m3.plan_flags = 0x4 if direct else 0
+    x2, y2 = crnn_ref.synthetic_batch(3, 2, 40, 32, 4, seed=5)
+    _oracle_vs_hip(sed, ref2, m3, x2, y2)
+
+
 def test_bf16x3_conv_experiment_stays_within_the_parity_tolerances(sed):
     """model.set_conv_precision("bf16x3") (explicit opt-in, not the default): the full-width golden g5 (K = 1152) and a
     C = 128 oracle comparison with the SAME tolerances as the exact-fp32 path; and the default is unchanged."""
