@@ -59,7 +59,7 @@ def pmc_traffic_bytes(prefix=None):
             continue
         tot, n = 0.0, 0
         for name, e in d.items():
-            if name.startswith(prefix or DOMINANT_PREFIX) and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:
+            if name.startswith(prefix or DOMINANT_PREFIX) and "false, 0, true" not in name and "FETCH_SIZE_KB_avg" in e and "WRITE_SIZE_KB_avg" in e:      # (not the inference instantiation)
                 k = int(e.get("launches", 1))
                 tot += k * (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024
                 n += k
@@ -367,7 +367,8 @@ def run_rank(args):
                     "roofline": {"bound": "mfma", "achieved": round(fl / (e_med * 1e-3) / 1e12, 2), "peak": peak_e, "unit": "TFLOP/s",
                                  "frac": round(fl / (e_med * 1e-3) / 1e12 / peak_e, 4), "flops_per_batch": fl,
                                  "ceiling_ms": round(fl / (peak_e * 1e12) * 1e3, 4),
-                                 "note": "whole eval forward (one packing launch, 3 conv blocks, 2 BiGRU layers, head) against the fp32 "
+                                 "note": "conv2 / conv3 run as Winograd F(2x2,3x3) with BatchNorm folded and ReLU + pool in the epilogue (16/36 of the algorithmic multiply-adds are executed, hence frac > 1); "
+                                         "whole eval forward (one packing launch, 3 conv blocks, 2 BiGRU layers, head) against the fp32 "
                                          "MFMA peak: 88 % of its FLOPs are conv2/conv3, exact fp32"}}
         model.train()
     rank_stats = None
@@ -464,17 +465,20 @@ def run_rank(args):
                 out["roofline"]["in_step_by_instantiation"] = {
                     "forward": _inst(ms_f, n_f, units_f),
                     "data gradient + BatchNorm-backward sums": _inst(ms_d, n_d, units_d),
-                    "note": "the forward launches have the GPU to themselves inside the step; the data gradient of conv2 runs while the "
-                            "top block's weight-gradient kernel (auxiliary stream) holds part of the CUs, so its event pair spans the "
-                            "work of both kernels: `frac` above averages over all four launches per step as the contract asks"}
+                    "note": ("every launch has the GPU to itself inside the step (the conv phase of the backward is serial on the main stream "
+                             "since the Winograd kernels); the data gradient's epilogue also forms the BatchNorm-backward sums of the block "
+                             "below and, for conv2, the first block's weight-gradient sums: `frac` above averages over all four launches per "
+                             "step as the contract asks") if wino else
+                            ("the forward launches have the GPU to themselves inside the step; the data gradient of conv2 runs while the "
+                             "top block's weight-gradient kernel (auxiliary stream) holds part of the CUs, so its event pair spans the "
+                             "work of both kernels: `frac` above averages over all four launches per step as the contract asks")}
             if n_x.value:
                 tf_x = units_x.value / (ms_x.value * 1e-3) / 1e12
                 out["roofline"]["alone"] = {
                     "achieved": round(tf_x, 2), "frac": round(tf_x / peak, 4), "avg_launch_ms": round(ms_x.value / n_x.value, 4),
                     "launches": n_x.value,
                     "note": "the forward instantiation, same two shapes, in 8 forward-only passes after the timed region (nothing else "
-                            "on the GPU); inside the step the data gradient of conv2 shares the CUs with the top block's weight "
-                            "gradient (auxiliary stream) for part of its run, which lengthens that launch and shortens the step"}
+                            "on the GPU)"}
         if eval_fwd is not None:
             out["eval_forward"] = eval_fwd
         if not args.no_cpu_baseline and world == 1:              # rank 0 at N = 1 only (a reported baseline, not part of the step)

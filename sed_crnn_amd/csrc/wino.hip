@@ -240,9 +240,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 
     const f32x4* wl = (const f32x4*)uq + (size_t)(coh * 16 + wave * 4) * (NCHUNK * 4 * 2 * 64);      // wave-uniform
     f32x4 bq[4][2];
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto load_b = [&](int nu, int st) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bq[nu][nt] = wl[((nu * NSTEP + st) * 2 + nt) * 64 + lane];
+        for (int nt = 0; nt < 2; ++nt)          // (scalar base + 32-bit lane offset: the address costs scalar adds, no vector instruction)
+            bq[nu][nt] = *(const f32x4*)((const char*)(wl + ((nu * NSTEP + st) * 2 + nt) * 64) + lane16);
     };
     f32x4 va[2][2][4];
     auto read_a = [&](const float* buf, int g, f32x4 (&v)[2][4]) {
