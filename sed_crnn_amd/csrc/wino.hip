@@ -115,6 +115,23 @@ int sed_internal_wino_rows(int B, int Cin, int F, int T, int Cout) {
     return wino_geo(B, Cin, F, T, Cout, &g) ? B * g.nblk * g.ncg : 0;
 }
 
+// packed fp32 pairs (see the kernel)
+__device__ __forceinline__ f32x2 wn_pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 wn_pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 wn_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // ───────────────────────── the kernel ─────────────────────────
 // RGC > 0 (data gradient of the block above the recomputed first block with RGC input channels, pool (1,2)): the epilogue also forms
 // that block's weight-gradient sums R_k from the gradient values in registers, exactly as the direct kernel's RG epilogue does
@@ -246,72 +263,77 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         for (int nt = 0; nt < 2; ++nt)          // (scalar base + 32-bit lane offset: the address costs scalar adds, no vector instruction)
             bq[nu][nt] = *(const f32x4*)((const char*)(wl + ((nu * NSTEP + st) * 2 + nt) * 64) + lane16);
     };
-    f32x4 va[2][2][4];
-    auto read_a = [&](const float* buf, int g, f32x4 (&v)[2][4]) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x4 u[4], dA[4], dB[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                dA[c] = *(const f32x4*)(buf + aoff[mt][0][c] + g * 64);
-                dB[c] = *(const f32x4*)(buf + aoff[mt][1][c] + g * 64);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) u[c] = dA[c] + sg * dB[c];
-            if (ABL & 1) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[mt][c] = dA[c] * dB[c][0];      // (one multiply per element keeps both reads alive)
-                continue;
-            }
-            v[mt][0] = u[0] - u[2];
-            v[mt][1] = u[1] + u[2];
-            v[mt][2] = u[2] - u[1];
-            v[mt][3] = u[1] - u[3];
+    // Operands of a step: vp[parity][mt][nu][half] — the four k values (j) of an MFMA group as two register PAIRS.  The input transform
+    // runs on pairs (v_pk_fma_f32 / v_pk_add_f32, written out: hipcc splits <2 x float> arithmetic into scalar instructions): beside the
+    // MFMAs an instruction costs its issue slot, not the vector ALU's time, so 32 instead of 64 per step.  Inline assembly is invisible to
+    // sched_group_barrier, so a step's instruction order is written out instead: after MFMA i of the 64 comes "slot i" —
+    //   slots 0-15   the 16 ds_read_b128 of the NEXT step's patch values (m-tile, row of the wave's row combination, column),
+    //   slots 16-47  its 32 transform instructions: per m-tile 8 x  u = d[ra] + sg d[rb]  then 8 x column combinations,
+    //   slot 16 nu + 15  the next step's two weight fragments of component nu (its MFMAs of this step have all been issued),
+    //   slots 1, 5, 9, ...  one patch DMA each in the first step of a slice
+    //   (measured alternatives, no better: the fragments one per slot at their last use, the DMA in the empty slots 49-62) —
+    // and a scheduling barrier after every slot keeps it that way.
+    static_assert(NH <= 16, "the patch DMA of a slice rides in every fourth slot of its first step");
+    f32x2 vp[2][2][4][2];
+    f32x4 raw[2][2][4];
+    f32x2 up[2][4][2];
+    const f32x2 sg2 = {sg, sg};
+    auto slot_read = [&](const float* buf, int g, int i) {                 // i = 0..15
+        const int mt = i >> 3, s2 = (i >> 2) & 1, c = i & 3;
+        raw[mt][s2][c] = *(const f32x4*)(buf + aoff[mt][s2][c] + g * 64);
+    };
+    auto slot_xform = [&](int k, f32x2 (&v)[2][4][2]) {                    // k = 0..31
+        const int mt = k >> 4, q = k & 15, hf = q & 1;
+        if (q < 8) {
+            const int c = q >> 1;
+            const f32x2 da = hf ? __builtin_shufflevector(raw[mt][0][c], raw[mt][0][c], 2, 3) : __builtin_shufflevector(raw[mt][0][c], raw[mt][0][c], 0, 1);
+            const f32x2 db = hf ? __builtin_shufflevector(raw[mt][1][c], raw[mt][1][c], 2, 3) : __builtin_shufflevector(raw[mt][1][c], raw[mt][1][c], 0, 1);
+            up[mt][c][hf] = wn_pk_fma(sg2, db, da);
+        } else {
+            const int nu = (q - 8) >> 1;
+            if (nu == 0) v[mt][0][hf] = wn_pk_sub(up[mt][0][hf], up[mt][2][hf]);
+            else if (nu == 1) v[mt][1][hf] = wn_pk_add(up[mt][1][hf], up[mt][2][hf]);
+            else if (nu == 2) v[mt][2][hf] = wn_pk_sub(up[mt][2][hf], up[mt][1][hf]);
+            else v[mt][3][hf] = wn_pk_sub(up[mt][1][hf], up[mt][3][hf]);
         }
+    };
+    auto issue_one = [&](int cc, float* buf, int u) {
+        __builtin_amdgcn_global_load_lds((sed_gptr_t)(hp[u] + cc * 32), (sed_lptr_t)(buf + (u * 4 + wave) * 256), 16, 0, 0);
     };
 
     issue(0, smem);
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) load_b(nu, 0);
     __syncthreads();                                   // drains the DMA (vmcnt)
-    read_a(smem, 0, va[0]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) slot_read(smem, 0, i);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) slot_xform(k, vp[0]);
     if (geo.dbg) tk1 = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
         const int cc = st >> 2, g = st & 3, par = st & 1;
-        const bool more = cc + 1 < NCHUNK;
+        const bool more = cc + 1 < NCHUNK, nxt = st + 1 < NSTEP;
+        const float* nbuf = smem + (((st + 1) >> 2) & 1) * HBUF;     // the next step's slice (the other buffer after step (cc, 3): complete since the barrier of (cc, 2))
         __builtin_amdgcn_sched_barrier(0);
-        if (g == 0 && more && !(ABL & 8)) issue(cc + 1, smem + ((cc + 1) & 1) * HBUF);      // that buffer was last read before the barrier of step (cc-1, 2)
-        if (st + 1 < NSTEP) {
-            if (ABL & 4) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) va[par ^ 1][a][c] = va[par][a][c];
-            } else read_a(smem + (((st + 1) >> 2) & 1) * HBUF, (st + 1) & 3, va[par ^ 1]);
-        }
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[par][mt][nu][j], bq[nu][nt][j], acc[nu][mt][nt], 0, 0, 0);
-            if (st + 1 < NSTEP && !(ABL & 2)) load_b(nu, st + 1);
-        }
-        // one MFMA, then up to two of the other instructions (transform arithmetic, LDS reads, fragment loads, DMA): one wave per
-        // SIMD issues in order, what sits between two MFMAs must fit the 64-cycle shadow of the one in front
-        // the 16 operand reads of the next step ride in the first 16 gaps, their arithmetic after them
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-            if ((i & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            const int nu = i >> 4, j = (i >> 2) & 3, mt = (i >> 1) & 1, nt = i & 1;
+            acc[nu][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[par][mt][nu][j >> 1][j & 1], bq[nu][nt][j], acc[nu][mt][nt], 0, 0, 0);
+            if (nxt && !(ABL & 4)) {
+                if (i < 16) slot_read(nbuf, (st + 1) & 3, i);
+                else if (i < 48 && !(ABL & 1)) slot_xform(i - 16, vp[par ^ 1]);
+            }
+            if (nxt && (i & 15) == 15 && !(ABL & 2)) load_b(nu, st + 1);
+            if (g == 0 && more && !(ABL & 8) && (i & 3) == 1 && (i >> 2) < NH) issue_one(cc + 1, smem + ((cc + 1) & 1) * HBUF, i >> 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (nxt && (ABL & 5)) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { vp[par ^ 1][a][c][0] = vp[par][a][c][0]; vp[par ^ 1][a][c][1] = vp[par][a][c][1]; }
+        }
         if (g == 2 && more) __syncthreads();           // the next slice's patch is complete (DMA drained) and visible
     }
     __syncthreads();                                   // every wave has read its last operands: the patch buffers are free
