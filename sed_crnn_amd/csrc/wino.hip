@@ -182,22 +182,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
     const int rb = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = wave == 1 ? 1.f : -1.f;
 
-    // LDS float offset of (patch position P, quad h) for the 2 m-tiles x 2 rows x 4 columns this lane reads every step
-    int aoff[2][2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int q = q0 + mt * 32 + r;
-        q = q < ntile ? q : ntile - 1;
-        const int ty = sed_fdiv(q, geo.invFw), tf = q - ty * Fw;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int P = (2 * (ty - ty0) + (s ? rb : ra)) * F2 + tf + (c & 1) * H2 + (c >> 1);
-                aoff[mt][s][c] = (P >> 3) * 256 + h * 32 + (P & 7) * 4;
-            }
-    }
-
     // patch staging (LDS-DMA): item = KiB block k = 4 u + wave, lane = 8 quad + position-in-block.  Every lane of every block issues
     // (no branch: the loads interleave with the MFMAs); a lane whose position is zero padding, or lies past the patch, reads the
     // zero tail behind the packed weights instead.
@@ -220,6 +204,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         for (int u = 0; u < NH; ++u)
             __builtin_amdgcn_global_load_lds((sed_gptr_t)(hp[u] + cc * 32), (sed_lptr_t)(buf + (u * 4 + wave) * 256), 16, 0, 0);
     };
+    // the first slice is requested before anything else is set up (its latency is the workgroup's prologue: 4.4 us)
+    issue(0, smem);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // LDS float offset of (patch position P, quad h) for the 2 m-tiles x 2 rows x 4 columns this lane reads every step
+    int aoff[2][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int q = q0 + mt * 32 + r;
+        q = q < ntile ? q : ntile - 1;
+        const int ty = sed_fdiv(q, geo.invFw), tf = q - ty * Fw;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int P = (2 * (ty - ty0) + (s ? rb : ra)) * F2 + tf + (c & 1) * H2 + (c >> 1);
+                aoff[mt][s][c] = (P >> 3) * 256 + h * 32 + (P & 7) * 4;
+            }
+    }
+
 
     // the epilogue's table: byte offset of output position (2 ty, 2 tf), channel 0, inside sequence b; ~0: no such tile
     unsigned* rowtab = (unsigned*)(smem + (2 * HBUF > 32768 + 512 ? 2 * HBUF : 32768 + 512));
@@ -301,7 +305,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
         __builtin_amdgcn_global_load_lds((sed_gptr_t)(hp[u] + cc * 32), (sed_lptr_t)(buf + (u * 4 + wave) * 256), 16, 0, 0);
     };
 
-    issue(0, smem);
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu) load_b(nu, 0);
     __syncthreads();                                   // drains the DMA (vmcnt)
