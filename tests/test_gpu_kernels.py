@@ -320,6 +320,48 @@ def test_conv3x3_winograd_forward_and_data_gradient(ops, B, Fm, T, Cout):
         assert float(derr.max()) < 4.0 * float(derr0.max()) + 2e-6 * float(dref.abs().mean()), (float(derr.max()), float(derr0.max()))
 
 
+def _wino_sweep_cases(n=28, seed=20260405):
+    import random
+    r = random.Random(seed)
+    out = []
+    while len(out) < n:
+        B = r.choice([1, 2, 3, 5, 8, 9, 16])
+        Fm = r.choice([2, 4, 6, 10, 12, 14, 20, 22, 26, 34, 40, 48, 64, 70, 128])
+        T = r.choice([2, 4, 6, 8, 10, 14, 18, 26, 32, 50])
+        Cout = r.choice([64, 128, 128, 192])
+        if B * Fm * T > 60000:
+            continue
+        out.append((B, Fm, T, Cout))
+    return out
+
+
+@pytest.mark.parametrize("B,Fm,T,Cout", _wino_sweep_cases())
+def test_conv3x3_winograd_seeded_shape_sweep(ops, B, Fm, T, Cout):
+    """28 seeded shapes through sed_conv3x3_wino_fwd (every shape the geometry takes must be right; the rest must say so): tile
+    rows of 1 to 64 tiles, blocks that straddle tile rows at every phase, column groups (mel 128 and 70: 35 tiles in one group),
+    a ragged last block, batch sizes on and off the XCD-aware order, 64 / 128 / 192 output channels — against torch in float64
+    with the bound of the fixed-shape test (the direct kernel's own error on the same inputs x 4 + an ulp term)."""
+    from sed_crnn_amd._lib import lib
+    rows = lib().sed_conv3x3_wino_rows(B, 128, Fm, T, Cout)
+    assert rows > 0, "every even (F, T) with 128 input channels and 64-multiples of output channels is taken"
+    gen = torch.Generator().manual_seed(B * 131 + Fm * 17 + T)
+    x = torch.randn(B, T, Fm, 128, generator=gen)
+    w = torch.randn(Cout, 128, 3, 3, generator=gen) / 34.0
+    bias = torch.randn(Cout, generator=gen)
+    ref = F.conv2d(x.permute(0, 3, 2, 1).double(), w.double(), bias.double(), padding=1).permute(0, 3, 2, 1).contiguous()
+    uf, _ = ops.conv3x3_wino_pack(g(w))
+    y, stat = ops.conv3x3_wino_fwd(g(x), uf, g(bias), Cout)
+    assert stat.shape[0] == rows
+    wf0, _ = ops.conv3x3_pack(g(w))
+    y0, _ = ops.conv3x3_fwd(g(x), wf0, g(bias), False)
+    scale = float(ref.abs().mean())
+    err, err0 = (y.cpu().double() - ref).abs(), (y0.cpu().double() - ref).abs()
+    assert float(err.max()) < 4.0 * float(err0.max()) + 2e-6 * scale, (float(err.max()), float(err0.max()), scale)
+    s = stat.sum(0).cpu().double()
+    torch.testing.assert_close(s[0], ref.sum((0, 1, 2)), rtol=1e-4, atol=2e-5 * scale * B * T * Fm)
+    torch.testing.assert_close(s[1], (ref * ref).sum((0, 1, 2)), rtol=1e-4, atol=1e-4 * B * T * Fm)
+
+
 @pytest.mark.parametrize("B,Ty,Fy,pf,pt,p", [(3, 16, 40, 1, 2, 0.5), (2, 12, 40, 1, 2, 0.0), (2, 8, 64, 1, 2, 0.5), (1, 8, 40, 2, 1, 0.25)])
 def test_winograd_dgrad_with_fused_bn_backward_reduction(ops, B, Ty, Fy, pf, pt, p):
     """sed_conv3x3_wino_dgrad_bnred against sed_conv3x3_dgrad_bnred (the direct kernel with the same epilogue): dx to the
