@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
                 zb1[row * 32 + r] = z1[j];
             }
         }
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);                 // (the exchange tiles are written: their registers are free for the pooled values)
     // across xi: wave w finishes m-tile w >> 1, channel tile w & 1; lane = (row group rq, channels c4 .. c4+3)
     const int mt = wave >> 1, nt = wave & 1;
     const int rq = lane >> 3, c4 = (lane & 7) * 4;
@@ -391,16 +391,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
 #pragma unroll
     for (int k = 0; k < (RG ? 9 * RGC : 1); ++k) R[k] = (f32x4){0, 0, 0, 0};
     const unsigned char* const bitq = RG ? br.bits + (size_t)b * T * F * (Cout >> 2) + (cb >> 2) : nullptr;
-    // BNR: the pooled values (and RG: the arg-max bytes) of a row's four output positions are requested one row ahead of their
-    // use — one dependent global load per position inside the loop below cost 8 us per workgroup
+    // BNR: the pooled values (and RG: the arg-max bytes) of this lane's output positions are requested ahead of their use — one
+    // dependent global load per position inside the loop below cost 8 us per workgroup, one row ahead still 4
     unsigned rov[4], xov[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         rov[k] = rowtab[mt * 32 + rq + 8 * k];
         xov[k] = RG ? xofftab[mt * 32 + rq + 8 * k] : 0u;
     }
-    f32x4 pqv[2][BNR ? 4 : 1];
-    unsigned btv[2][RG ? 4 : 1];
+    // (all four rows at once, in front of the exchange barrier: 16 loads in flight together instead of four dependent rounds;
+    // two input channels: 72 tap accumulators leave room for two rows only)
+    constexpr int PF = RGC == 2 ? 2 : 4;
+    f32x4 pqv[PF][BNR ? 4 : 1];
+    unsigned btv[PF][RG ? 4 : 1];
     auto prefetch = [&](int k, f32x4* pqd, unsigned* btd) {
         if (!BNR) return;
 #pragma unroll
@@ -416,12 +419,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
                 }
             }
     };
-    prefetch(0, pqv[0], btv[0]);
+    if (PF == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prefetch(k, pqv[k], btv[k]);
+    } else prefetch(0, pqv[0], btv[0]);
+
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int m = rq + 8 * k;
         const unsigned ro = rov[k];
-        if (k + 1 < 4) prefetch(k + 1, pqv[(k + 1) & 1], btv[(k + 1) & 1]);
+        if (PF == 2 && k + 1 < 4) prefetch(k + 1, pqv[(k + 1) & 1], btv[(k + 1) & 1]);
         if (ro == 0xFFFFFFFFu) continue;
         const unsigned xo = xov[k];
 #pragma unroll
@@ -443,14 +451,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_k(
                 const f32x4 v = o[i];
                 *(f32x4*)(yb + off) = v;
                 if (BNR) {
-                    const f32x4 pq = pqv[k & 1][jj * 2 + i];
+                    const f32x4 pq = pqv[k & (PF - 1)][jj * 2 + i];
                     f32x4 g0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g0[e] = pq[e] > 0.f ? v[e] : 0.f;
                     a1 += g0;
                     a2 += g0 * (pq * q_kr + q_nb);
                     if (RG) {
-                        const unsigned bt = btv[k & 1][jj * 2 + i];
+                        const unsigned bt = btv[k & (PF - 1)][jj * 2 + i];
                         f32x4 g1;                         // the share of the window's second time row
 #pragma unroll
                         for (int e = 0; e < 4; ++e) g1[e] = ((bt >> e) & 1u) ? g0[e] : 0.f;
