@@ -1028,3 +1028,41 @@ def test_conv3x3_forward_is_bitwise_stable_under_memory_pressure(ops, mode):
         y, st = ops.conv3x3_fwd(x, wf, bias, False, mode=mode)
         assert torch.equal(y, y0) and torch.equal(st, st0), it
     torch.cuda.synchronize()
+
+
+def test_winograd_kernels_are_bitwise_stable_under_memory_pressure(ops):
+    """The Winograd kernels leave every wait to hipcc, but their patch arrives by LDS-DMA (counted in vmcnt) under a written-out
+    instruction order with one barrier per slice, and the weight gradient stages its tiles through registers two chunks ahead of
+    their commit: a read that overtakes its data would depend on memory latency.  Same protocol as above: forward, data gradient
+    with the BatchNorm epilogue and weight gradient are repeated while a second stream streams 1 GB copies through HBM, and every
+    result must equal the first bit for bit."""
+    torch.manual_seed(4)
+    B, T, Fm, Cc = 32, 64, 40, 128
+    x = torch.randn(B, T, Fm, Cc, device="cuda")
+    dy = torch.randn(B, T, Fm, Cc, device="cuda") * 0.1
+    w = torch.randn(Cc, Cc, 3, 3, device="cuda") / 34.0
+    bias = torch.randn(Cc, device="cuda")
+    uf, ud = ops.conv3x3_wino_pack(w)
+    gamma, beta = torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda") * 0.2
+    yb = torch.randn(B, 2 * T, Fm, Cc, device="cuda")                       # conv output of the block below, pool (1,2)
+    flat = yb.reshape(-1, Cc)
+    part = torch.stack([flat.sum(0), (flat ** 2).sum(0)]).reshape(1, 2, Cc).contiguous()
+    mean, rstd, scale, shift = ops.bn_finalize_train(part, flat.shape[0], gamma, beta, torch.zeros(Cc).cuda(), torch.ones(Cc).cuda())
+    pooled = ops.bn_relu_pool_drop_fwd(yb, scale, shift, 1, 2, drop_p=0.5, seed=5)
+
+    def run():
+        y, st = ops.conv3x3_wino_fwd(x, uf, bias, Cc)
+        dx, sg, sgx = ops.conv3x3_dgrad_bnred(dy, ud, pooled, gamma, beta, yb, mean, rstd, 1, 2, drop_p=0.5, scale=scale, shift=shift, wino=True)
+        dw = ops.conv3x3_wgrad(x, dy, False)
+        return [t.clone() for t in (y, st, dx, sg, sgx, dw)]
+
+    first = run()
+    big = torch.empty(256 << 20, device="cuda")          # 1 GiB
+    side = torch.cuda.Stream()
+    for it in range(16):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                big[: 128 << 20].copy_(big[128 << 20:], non_blocking=True)
+        for a, b_ in zip(run(), first):
+            assert torch.equal(a, b_), it
+    torch.cuda.synchronize()
